@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE ITSELF (build container only).
+
+Imports /root/reference's own DDPM + denoising_step (they need only torch/numpy),
+loads hash-generated weights (oracle.weights — nothing is stored but the outputs),
+and records reference outputs as .npz fixtures next to this script:
+
+  ddpm_small.npz   small DDPM (ch=32, 32x32): forwards, single steps, a 6+6-step edit
+  ddpm_celeba.npz  full CelebA-HQ DDPM (256x256, B=1): one single + one dual forward,
+                   one Asyrp step, DeltaBlock = hash weights
+
+Run:  python tests/golden/make_golden.py      (needs /root/reference; ~1 min on 8 cores)
+"""
+import argparse
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("ASYRP_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from oracle.weights import (CELEBA, SMALL, ddpm_param_shapes, hash_normal, hash_uniform,  # noqa: E402
+                            synthetic_state_dict)
+
+
+def ref_model(cfg, sd, n_delta=1):
+    from models.ddpm.diffusion import DDPM
+    ns = Namespace(
+        model=Namespace(ch=cfg.ch, out_ch=cfg.out_ch, ch_mult=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks,
+                        attn_resolutions=list(cfg.attn_resolutions), dropout=0.0, in_channels=cfg.in_channels,
+                        resamp_with_conv=True),
+        data=Namespace(image_size=cfg.resolution))
+    m = DDPM(ns)
+    m.setattr_layers(n_delta)
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.eval()
+
+
+def run_small(out):
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(1)
+    cfg = SMALL
+    sd = synthetic_state_dict(ddpm_param_shapes(cfg, n_delta=2), seed=7)
+    m = ref_model(cfg, sd, n_delta=2)
+    B = 2
+    x = hash_normal("small.x", (B, 3, 32, 32), seed=1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    logvars = np.zeros(1000)
+    g = {}
+    with torch.no_grad():
+        t = torch.ones(B) * 701.0
+        et, _, _, mh = m(x, t)
+        g["fwd_single.et"], g["fwd_single.middle_h"] = et, mh
+        et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
+        et, em, dh, mh = m(x, t, index=1, t_edit=500, hs_coeff=(0.9, 0.7, 0.5))   # two DeltaBlocks (multi-attr)
+        g["fwd_multi.et"], g["fwd_multi.et_mod"], g["fwd_multi.delta_h"] = et, em, dh
+        et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0), ignore_timestep=True)
+        g["fwd_ignoret.et_mod"], g["fwd_ignoret.delta_h"] = em, dh
+        t2 = torch.ones(B) * 204.0
+        et, em, dh, mh = m(x, t2, index=0, t_edit=500, hs_coeff=(1.0, 1.0))       # t < t_edit: h2 = h
+        assert dh is None and torch.equal(et, em)
+        g["fwd_noedit.et"] = et
+        # single steps through the reference's denoising_step
+        kw = dict(models=m, logvars=logvars, b=betas, sampling_type="ddim")
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 0.0, t_next=torch.ones(B) * 25.0, eta=0, **kw)
+        g["step_inv.xt_next"], g["step_inv.x0_t"] = xn, x0t
+        xn, x0t, dh, mh = denoising_step(x, t=t, t_next=torch.ones(B) * 675.0, eta=0.0, index=0, t_edit=500,
+                                         hs_coeff=(1.0, 1.0), **kw)
+        g["step_gen.xt_next"], g["step_gen.x0_t"], g["step_gen.delta_h"] = xn, x0t, dh
+        torch.manual_seed(99)
+        z = torch.randn_like(x)
+        torch.manual_seed(99)
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 25.0, t_next=torch.ones(B) * 0.0, eta=1.0, index=0,
+                                       t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        g["step_eta.noise"], g["step_eta.xt_next"], g["step_eta.x0_t"] = z, xn, x0t
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 0.0, t_next=torch.ones(B) * -1.0, eta=0.0, index=0,
+                                       t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        g["step_last.xt_next"], g["step_last.x0_t"] = xn, x0t
+        xn, x0t, _, _ = denoising_step(x, t=t, t_next=torch.ones(B) * 675.0, eta=0.0, index=0, t_edit=500,
+                                       hs_coeff=(1.0, 1.0), dt_lambda=1.05, dt_end=600, **kw)
+        g["step_dt.xt_next"] = xn
+        # whole edit, 6 inversion + 6 generation steps (same loop shapes as 40/40)
+        n_step, t_0, t_edit = 6, 999, 500
+        seq = [int(s + 1e-6) for s in list(np.linspace(0, 1, n_step) * t_0)]
+        seq_next = [-1] + seq[:-1]
+        xx = x.clone()
+        for i, j in zip(seq_next[1:], seq[1:]):
+            xx, _, _, _ = denoising_step(xx, t=torch.ones(B) * i, t_next=torch.ones(B) * j, eta=0, **kw)
+        g["edit.x_T"] = xx.clone()
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            xx, x0t, _, _ = denoising_step(xx, t=torch.ones(B) * i, t_next=torch.ones(B) * j, eta=0.0, index=0,
+                                           t_edit=t_edit, hs_coeff=(1.0, 1.0), **kw)
+        g["edit.x_edit"] = xx
+    g["input.x"] = x
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_celeba(out):
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    cfg = CELEBA
+    sd = synthetic_state_dict(ddpm_param_shapes(cfg, n_delta=1), seed=1234)
+    m = ref_model(cfg, sd, n_delta=1)
+    x = hash_normal("celeba.x", (1, 3, 256, 256), seed=1234)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = {}
+    with torch.no_grad():
+        t = torch.ones(1) * 768.0
+        et, _, _, mh = m(x, t)
+        g["fwd_single.et"], g["fwd_single.middle_h"] = et, mh
+        et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"] = et, em, dh
+        xn, x0t, _, _ = denoising_step(x, t=t, t_next=torch.ones(1) * 743.0, models=m, logvars=np.zeros(1000),
+                                       b=betas, sampling_type="ddim", eta=0.0, index=0, t_edit=500,
+                                       hs_coeff=(1.0, 1.0))
+        g["step_gen.xt_next"], g["step_gen.x0_t"] = xn, x0t
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=["small", "celeba"], default=None)
+    a = ap.parse_args()
+    if a.only in (None, "small"):
+        run_small(os.path.join(HERE, "ddpm_small.npz"))
+    if a.only in (None, "celeba"):
+        run_celeba(os.path.join(HERE, "ddpm_celeba.npz"))

@@ -1,0 +1,110 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz,
+produced by tests/golden/make_golden.py from /root/reference)."""
+import numpy as np
+import torch
+
+from conftest import assert_close
+from oracle import sampler
+from oracle.ddpm import ddpm_forward
+from oracle.weights import CELEBA, SMALL, ddpm_param_shapes, hash_normal, synthetic_state_dict
+
+TIGHT = dict(rtol=1e-5, atol=2e-6)   # same math, same library: only summation-order noise
+
+
+def _small():
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(ddpm_param_shapes(SMALL, n_delta=2), seed=7)
+    x = hash_normal("small.x", (2, 3, 32, 32), seed=1)
+    return sd, x
+
+
+def test_hash_inputs_are_stable(golden_small):
+    _, x = _small()
+    assert torch.equal(x, golden_small["input.x"])
+
+
+def test_forward_single_and_dual(golden_small):
+    sd, x = _small()
+    g = golden_small
+    t = torch.ones(2) * 701.0
+    with torch.no_grad():
+        et, em, dh, mh = ddpm_forward(sd, SMALL, x, t)
+        assert em is None and dh is None
+        assert_close(et, g["fwd_single.et"], what="et", **TIGHT)
+        assert_close(mh, g["fwd_single.middle_h"], what="middle_h", **TIGHT)
+        et, em, dh, mh = ddpm_forward(sd, SMALL, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        assert_close(et, g["fwd_dual.et"], what="et", **TIGHT)
+        assert_close(em, g["fwd_dual.et_mod"], what="et_mod", **TIGHT)
+        assert_close(dh, g["fwd_dual.delta_h"], what="delta_h", **TIGHT)
+        assert_close(mh, g["fwd_dual.middle_h"], what="middle_h", **TIGHT)
+
+
+def test_forward_variants(golden_small):
+    sd, x = _small()
+    g = golden_small
+    t = torch.ones(2) * 701.0
+    with torch.no_grad():
+        et, em, dh, _ = ddpm_forward(sd, SMALL, x, t, index=1, t_edit=500, hs_coeff=(0.9, 0.7, 0.5))
+        assert_close(em, g["fwd_multi.et_mod"], what="multi et_mod", **TIGHT)
+        assert_close(dh, g["fwd_multi.delta_h"], what="multi delta_h", **TIGHT)
+        _, em, dh, _ = ddpm_forward(sd, SMALL, x, t, index=0, t_edit=500, ignore_timestep=True)
+        assert_close(em, g["fwd_ignoret.et_mod"], what="ignore_timestep et_mod", **TIGHT)
+        assert_close(dh, g["fwd_ignoret.delta_h"], what="ignore_timestep delta_h", **TIGHT)
+        et, em, dh, _ = ddpm_forward(sd, SMALL, x, torch.ones(2) * 204.0, index=0, t_edit=500)
+        assert dh is None and torch.equal(et, em)
+        assert_close(et, g["fwd_noedit.et"], what="noedit et", **TIGHT)
+
+
+def test_steps(golden_small):
+    sd, x = _small()
+    g = golden_small
+    model = sampler.make_model(sd, SMALL)
+    b = sampler.beta_schedule()
+    one = torch.ones(2)
+    xn, x0t, _, _ = sampler.denoising_step(x, one * 0.0, one * 25.0, model=model, b=b, eta=0)
+    assert_close(xn, g["step_inv.xt_next"], what="inv xt_next", **TIGHT)
+    assert_close(x0t, g["step_inv.x0_t"], what="inv x0_t", **TIGHT)
+    kw = dict(model=model, b=b, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    xn, x0t, dh, _ = sampler.denoising_step(x, one * 701.0, one * 675.0, eta=0.0, **kw)
+    assert_close(xn, g["step_gen.xt_next"], what="gen xt_next", **TIGHT)
+    assert_close(x0t, g["step_gen.x0_t"], what="gen x0_t", **TIGHT)
+    assert_close(dh, g["step_gen.delta_h"], what="gen delta_h", **TIGHT)
+    xn, x0t, _, _ = sampler.denoising_step(x, one * 25.0, one * 0.0, eta=1.0, noise=g["step_eta.noise"], **kw)
+    assert_close(xn, g["step_eta.xt_next"], what="eta xt_next", **TIGHT)
+    xn, x0t, _, _ = sampler.denoising_step(x, one * 0.0, one * -1.0, eta=0.0, **kw)
+    assert_close(xn, g["step_last.xt_next"], what="last xt_next", **TIGHT)
+    assert_close(x0t, g["step_last.x0_t"], what="last x0_t", **TIGHT)
+    xn, _, _, _ = sampler.denoising_step(x, one * 701.0, one * 675.0, eta=0.0, dt_lambda=1.05, dt_end=600, **kw)
+    assert_close(xn, g["step_dt.xt_next"], what="dt_lambda xt_next", **TIGHT)
+
+
+def test_whole_edit_loop(golden_small):
+    sd, x = _small()
+    g = golden_small
+    model = sampler.make_model(sd, SMALL)
+    b = sampler.beta_schedule()
+    x_T = sampler.invert(model, x, b, n_inv=6)
+    assert_close(x_T, g["edit.x_T"], what="x_T", rtol=1e-4, atol=1e-5)
+    x_e = sampler.generate(model, x_T, b, n_gen=6, t_edit=500, t_addnoise=0)
+    assert_close(x_e, g["edit.x_edit"], what="x_edit", rtol=1e-4, atol=1e-5)
+
+
+def test_timestep_sequence_matches_reference_values():
+    seq, nxt = sampler.timestep_seq(40, 999)
+    assert seq[:4] == [0, 25, 51, 76] and seq[-2:] == [973, 999] and nxt[0] == -1 and len(seq) == 40
+    ab = sampler.alpha_bar(sampler.beta_schedule())
+    assert ab.dtype == torch.float32 and abs(float(ab[999]) - 4.0358e-05) < 1e-7
+
+
+def test_full_size_forward_against_reference(golden_celeba):
+    """One 256x256 dual forward of the CelebA-HQ DDPM (114 M params) — ~3 s on 8 cores."""
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    x = hash_normal("celeba.x", (1, 3, 256, 256), seed=1234)
+    with torch.no_grad():
+        et, em, dh, mh = ddpm_forward(sd, CELEBA, x, torch.ones(1) * 768.0, index=0, t_edit=500)
+    g = golden_celeba
+    loose = dict(rtol=1e-4, atol=1e-5)   # oneDNN blocking differs with thread count
+    assert_close(et, g["fwd_dual.et"], what="et", **loose)
+    assert_close(em, g["fwd_dual.et_mod"], what="et_mod", **loose)
+    assert_close(dh, g["fwd_dual.delta_h"], what="delta_h", **loose)
