@@ -1,0 +1,80 @@
+"""ctypes binding of libasyrp_hip.so (the C ABI in include/asyrp.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the compute
+entry points raises.  torch is imported first so the process shares torch's HIP runtime
+(libamdhip64.so.7 is resolved by SONAME to the already-loaded copy).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasyrp_hip.so")
+
+MAX_LEVELS = 8
+FAMILY_DDPM, FAMILY_IDDPM = 0, 1
+
+
+class AsyrpConfig(C.Structure):
+    _fields_ = [("family", C.c_int32), ("resolution", C.c_int32), ("in_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("ch", C.c_int32), ("n_levels", C.c_int32),
+                ("ch_mult", C.c_int32 * MAX_LEVELS), ("num_res_blocks", C.c_int32), ("n_attn", C.c_int32),
+                ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("num_head_channels", C.c_int32),
+                ("n_delta", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+_P, _F, _I = C.c_void_p, C.c_float, C.c_int
+_SIGS = {
+    "asyrp_abi_version": (C.c_int, []),
+    "asyrp_last_error": (C.c_char_p, []),
+    "asyrp_create": (C.c_int, [C.POINTER(_P), C.POINTER(AsyrpConfig), _I, _I]),
+    "asyrp_destroy": (None, [_P]),
+    "asyrp_load_param": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "asyrp_set_schedule": (C.c_int, [_P, _P, _I]),
+    "asyrp_set_temb_freqs": (C.c_int, [_P, _P, _I]),
+    "asyrp_finalize_params": (C.c_int, [_P]),
+    "asyrp_num_params": (C.c_int, [_P]),
+    "asyrp_param_info": (C.c_int, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
+    "asyrp_unet_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "asyrp_ddim_step": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "asyrp_run_edit": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "asyrp_device_bytes": (C.c_int64, [_P]),
+    "asyrp_profile_enable": (C.c_int, [_P, _I]),
+    "asyrp_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
+    "asyrp_op_conv2d": (C.c_int, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P,
+                                  _P, _P]),
+    "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every signature.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the Asyrp HIP engine has no CPU/PyTorch fallback. "
+            "Build it with `python -m asyrp_official_amd.build` (needs hipcc, targets gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError here == ABI mismatch; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AsyrpError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().asyrp_last_error().decode(errors="replace")
+        raise AsyrpError(f"asyrp engine error {rc}: {msg}")

@@ -1,0 +1,1025 @@
+// engine.hip — host side of libasyrp_hip.so: parameter store, workspace pool, UNet schedule, the
+// DDIM loops and the C ABI declared in include/asyrp.h.  No torch, no CPU compute fallback: every
+// arithmetic op of the hot path is a launch of a kernel from kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/asyrp.h"
+#include "kernels.h"
+
+using namespace asyrp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t _e = (x);                                                                            \
+    if (_e != hipSuccess) return fail(ASYRP_EHIP, std::string(#x) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+#define TRY(x)            \
+  do {                    \
+    int _r = (x);         \
+    if (_r != 0) return _r; \
+  } while (0)
+
+struct ParamSpec {
+  std::string key;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    return n;
+  }
+};
+
+// ---- device workspace pool: size-keyed free lists; single in-order stream makes immediate reuse safe ----
+struct Pool {
+  std::multimap<size_t, float*> free_;
+  std::unordered_map<float*, size_t> size_;
+  size_t total_bytes = 0;
+  int get(size_t nfloats, float** out) {
+    if (nfloats == 0) nfloats = 1;
+    nfloats = (nfloats + 63) & ~(size_t)63;
+    auto it = free_.find(nfloats);
+    if (it != free_.end()) {
+      *out = it->second;
+      free_.erase(it);
+      return 0;
+    }
+    float* p = nullptr;
+    hipError_t e = hipMalloc(&p, nfloats * sizeof(float));
+    if (e != hipSuccess) return fail(ASYRP_EHIP, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+    size_[p] = nfloats;
+    total_bytes += nfloats * sizeof(float);
+    *out = p;
+    return 0;
+  }
+  void put(float* p) {
+    if (!p) return;
+    auto it = size_.find(p);
+    if (it != size_.end()) free_.emplace(it->second, p);
+  }
+  void destroy() {
+    for (auto& kv : size_) (void)hipFree(kv.first);
+    size_.clear();
+    free_.clear();
+    total_bytes = 0;
+  }
+};
+
+struct Act {
+  float* p = nullptr;
+  int C = 0, H = 0, W = 0;
+  long long per_image() const { return (long long)H * W * C; }
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int variant;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct asyrp_engine {
+  asyrp_config cfg;
+  int max_batch = 0, device = 0;
+  std::vector<ParamSpec> specs;
+  std::unordered_map<std::string, int> spec_idx;
+  std::vector<std::vector<float>> host;
+  std::vector<char> loaded;
+  bool finalized = false;
+
+  std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
+  size_t param_bytes = 0;
+  std::unordered_map<std::string, int> tproj_off;   // ResnetBlock / DeltaBlock prefix -> column in tproj
+  int tproj_total = 0;
+  int temb_ch = 0, bott_ch = 0, bott_res = 0;
+  std::vector<float> alphas;
+  float* d_freqs = nullptr;
+  int n_freqs = 0;
+  float* d_t = nullptr;   // [max_batch] timesteps for the fused step / loops
+  Pool pool;
+
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// parameter inventory of the reference DDPM (models/ddpm/diffusion.py:327-444), state_dict names
+// ---------------------------------------------------------------------------------------------------
+struct SpecBuilder {
+  std::vector<ParamSpec>& v;
+  void conv(const std::string& p, int cin, int cout, int k) {
+    v.push_back({p + ".weight", {cout, cin, k, k}});
+    v.push_back({p + ".bias", {cout}});
+  }
+  void lin(const std::string& p, int cin, int cout) {
+    v.push_back({p + ".weight", {cout, cin}});
+    v.push_back({p + ".bias", {cout}});
+  }
+  void norm(const std::string& p, int c) {
+    v.push_back({p + ".weight", {c}});
+    v.push_back({p + ".bias", {c}});
+  }
+  void res(const std::string& p, int cin, int cout, int temb) {
+    norm(p + ".norm1", cin);
+    conv(p + ".conv1", cin, cout, 3);
+    lin(p + ".temb_proj", temb, cout);
+    norm(p + ".norm2", cout);
+    conv(p + ".conv2", cout, cout, 3);
+    if (cin != cout) conv(p + ".nin_shortcut", cin, cout, 1);
+  }
+  void attn(const std::string& p, int c) {
+    norm(p + ".norm", c);
+    conv(p + ".q", c, c, 1);
+    conv(p + ".k", c, c, 1);
+    conv(p + ".v", c, c, 1);
+    conv(p + ".proj_out", c, c, 1);
+  }
+};
+
+bool has_attn(const asyrp_config& c, int res) {
+  for (int i = 0; i < c.n_attn; ++i)
+    if (c.attn_resolutions[i] == res) return true;
+  return false;
+}
+
+std::string S(const char* fmt, int a = 0, int b = 0) {
+  char buf[128];
+  snprintf(buf, sizeof buf, fmt, a, b);
+  return buf;
+}
+
+void build_specs_ddpm(asyrp_engine* e) {
+  const asyrp_config& c = e->cfg;
+  SpecBuilder sb{e->specs};
+  const int ch = c.ch, temb = c.ch * 4, L = c.n_levels;
+  auto in_mult = [&](int i) { return i == 0 ? 1 : c.ch_mult[i - 1]; };
+  sb.lin("temb.dense.0", ch, temb);
+  sb.lin("temb.dense.1", temb, temb);
+  sb.conv("conv_in", c.in_channels, ch, 3);
+  int res = c.resolution, block_in = ch;
+  for (int i = 0; i < L; ++i) {
+    block_in = ch * in_mult(i);
+    const int block_out = ch * c.ch_mult[i];
+    for (int j = 0; j < c.num_res_blocks; ++j) {
+      sb.res(S("down.%d.block.%d", i, j), block_in, block_out, temb);
+      block_in = block_out;
+      if (has_attn(c, res)) sb.attn(S("down.%d.attn.%d", i, j), block_in);
+    }
+    if (i != L - 1) {
+      sb.conv(S("down.%d.downsample.conv", i), block_in, block_in, 3);
+      res /= 2;
+    }
+  }
+  sb.res("mid.block_1", block_in, block_in, temb);
+  sb.attn("mid.attn_1", block_in);
+  sb.res("mid.block_2", block_in, block_in, temb);
+  e->bott_ch = block_in;
+  e->bott_res = res;
+  e->temb_ch = temb;
+  // decoder is constructed deepest level first but named up.0 .. up.L-1 (diffusion.py:399-423)
+  std::vector<std::vector<ParamSpec>> ups(L);
+  for (int i = L - 1; i >= 0; --i) {
+    SpecBuilder ub{ups[i]};
+    const int block_out = ch * c.ch_mult[i];
+    int skip_in = ch * c.ch_mult[i];
+    for (int j = 0; j < c.num_res_blocks + 1; ++j) {
+      if (j == c.num_res_blocks) skip_in = ch * in_mult(i);
+      ub.res(S("up.%d.block.%d", i, j), block_in + skip_in, block_out, temb);
+      block_in = block_out;
+      if (has_attn(c, res)) ub.attn(S("up.%d.attn.%d", i, j), block_in);
+    }
+    if (i != 0) {
+      ub.conv(S("up.%d.upsample.conv", i), block_in, block_in, 3);
+      res *= 2;
+    }
+  }
+  for (int i = 0; i < L; ++i)
+    for (auto& s : ups[i]) e->specs.push_back(s);
+  sb.norm("norm_out", block_in);
+  sb.conv("conv_out", block_in, c.out_channels, 3);
+  for (int d = 0; d < c.n_delta; ++d) {   // DeltaBlock (diffusion.py:228-263)
+    const std::string p = S("layer_%d", d);
+    sb.conv(p + ".conv1", e->bott_ch, e->bott_ch, 1);
+    sb.lin(p + ".temb_proj", temb, e->bott_ch);
+    sb.norm(p + ".norm2", e->bott_ch);
+    sb.conv(p + ".conv2", e->bott_ch, e->bott_ch, 1);
+  }
+}
+
+bool ends_with(const std::string& s, const std::string& suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+int upload(asyrp_engine* e, const std::string& name, const std::vector<float>& v) {
+  float* d = nullptr;
+  auto it = e->dev.find(name);
+  if (it != e->dev.end()) {
+    d = it->second;
+  } else {
+    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(float)));
+    e->dev[name] = d;
+    e->param_bytes += v.size() * sizeof(float);
+  }
+  HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+const std::vector<float>& hostp(asyrp_engine* e, const std::string& key) { return e->host[e->spec_idx.at(key)]; }
+
+// conv weight [Cout][Cin][k][k] -> GEMM B operand [k*k][Cin][Cout]
+std::vector<float> pack_conv(const std::vector<float>& w, int cout, int cin, int k) {
+  std::vector<float> o((size_t)k * k * cin * cout);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < k * k; ++t) o[((size_t)t * cin + ci) * cout + co] = w[((size_t)co * cin + ci) * k * k + t];
+  return o;
+}
+
+struct Ctx {
+  asyrp_engine* e;
+  hipStream_t s;
+  int B;
+  float* tproj = nullptr;   // [B][tproj_total]
+};
+
+float* P(Ctx& c, const std::string& name) {
+  auto it = c.e->dev.find(name);
+  return it == c.e->dev.end() ? nullptr : it->second;
+}
+
+int new_act(Ctx& c, int C, int H, int W, Act* a) {
+  a->C = C;
+  a->H = H;
+  a->W = W;
+  return c.e->pool.get((size_t)c.B * H * W * C, &a->p);
+}
+void drop(Ctx& c, Act& a) {
+  c.e->pool.put(a.p);
+  a.p = nullptr;
+}
+
+int variant_of(const GemmArgs& g) { return g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0); }
+
+int run_gemm(Ctx& c, const GemmArgs& g) {
+  asyrp_engine* e = c.e;
+  if (e->prof_on) {
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!e->ev_free.empty()) {
+      ev = e->ev_free.back();
+      e->ev_free.pop_back();
+    } else {
+      HIPCHK(hipEventCreate(&ev.first));
+      HIPCHK(hipEventCreate(&ev.second));
+    }
+    ProfRec r;
+    r.a = ev.first;
+    r.b = ev.second;
+    r.variant = variant_of(g);
+    gemm_work(g, &r.flops, &r.bytes);
+    HIPCHK(hipEventRecord(r.a, c.s));
+    HIPCHK(launch_gemm(g, c.s));
+    HIPCHK(hipEventRecord(r.b, c.s));
+    e->prof.push_back(r);
+    return 0;
+  }
+  HIPCHK(launch_gemm(g, c.s));
+  return 0;
+}
+
+// y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
+int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
+         int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
+         const Act* resid, Act* out) {
+  const int Hin = x0.H, Win = x0.W;
+  int Ho = Hin, Wo = Win;
+  if (ups) { Ho *= 2; Wo *= 2; }
+  if (stride == 2) { Ho /= 2; Wo /= 2; }
+  TRY(new_act(c, Cout, Ho, Wo, out));
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = x0.p; g.c0 = x0.C; g.lda0 = x0.C; g.a0_zo = x0.per_image();
+  if (x1) { g.a1 = x1->p; g.c1 = x1->C; g.lda1 = x1->C; g.a1_zo = x1->per_image(); }
+  g.Hin = Hin; g.Win = Win; g.Hout = Ho; g.Wout = Wo;
+  g.Cin = x0.C + (x1 ? x1->C : 0);
+  g.Cout = Cout;
+  g.ks = ks; g.stride = stride; g.ups = ups;
+  g.pad = (ks == 3 && stride == 1) ? 1 : 0;   // stride 2: pad right/bottom only (diffusion.py:105)
+  g.pscale = pscale; g.pshift = pshift; g.silu = silu;
+  g.w = P(c, wname);
+  if (!g.w) return fail(ASYRP_EKEY, "missing packed weight " + wname);
+  g.ldb = Cout;
+  g.bias = bname.empty() ? nullptr : P(c, bname);
+  g.chan_add = chan_add; g.ld_chan_add = c.e->tproj_total;
+  if (resid) { g.resid = resid->p; g.ldr = resid->C; g.r_zo = resid->per_image(); }
+  g.alpha = 1.0f;
+  g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
+  g.ZI = 1; g.Z = c.B;
+  return run_gemm(c, g);
+}
+
+// GroupNorm(32, eps) statistics of (x0|x1) -> scale/shift [B][C] (pool buffers returned to the caller)
+int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float eps, float** scale, float** shift) {
+  const int C = x0.C + (x1 ? x1->C : 0);
+  const int HW = x0.H * x0.W;
+  TRY(c.e->pool.get((size_t)c.B * C, scale));
+  TRY(c.e->pool.get((size_t)c.B * C, shift));
+  float* part = nullptr;
+  TRY(c.e->pool.get(gn_partial_doubles(c.B, C, HW) * 2, &part));
+  GnArgs a;
+  memset(&a, 0, sizeof a);
+  a.a0 = x0.p; a.c0 = x0.C; a.lda0 = x0.C; a.a0_z = x0.per_image();
+  if (x1) { a.a1 = x1->p; a.c1 = x1->C; a.lda1 = x1->C; a.a1_z = x1->per_image(); }
+  a.HW = HW; a.N = c.B; a.C = C;
+  a.gamma = P(c, prefix + ".weight");
+  a.beta = P(c, prefix + ".bias");
+  if (!a.gamma || !a.beta) return fail(ASYRP_EKEY, "missing norm params " + prefix);
+  a.eps = eps;
+  a.scale = *scale; a.shift = *shift;
+  a.partial = reinterpret_cast<double*>(part);
+  HIPCHK(launch_gn(a, c.s));
+  c.e->pool.put(part);
+  return 0;
+}
+
+// ResnetBlock (models/ddpm/diffusion.py:151-170) on the virtual concat (x0|x1)
+int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* out) {
+  asyrp_engine* e = c.e;
+  const int Cin = x0.C + (x1 ? x1->C : 0);
+  const int Cout = (int)e->specs[e->spec_idx.at(p + ".conv1.bias")].shape[0];
+  float *sc1, *sh1, *sc2, *sh2;
+  TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1));
+  Act h1;
+  TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
+           c.tproj + e->tproj_off.at(p), nullptr, &h1));
+  e->pool.put(sc1); e->pool.put(sh1);
+  TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2));
+  Act sc;
+  bool own_sc = false;
+  if (Cin != Cout) {
+    TRY(conv(c, x0, x1, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", Cout, 1, 1, 0, nullptr, nullptr, 0,
+             nullptr, nullptr, &sc));
+    own_sc = true;
+  } else {
+    sc = x0;   // identity shortcut never has a concat input
+  }
+  TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sc, out));
+  e->pool.put(sc2); e->pool.put(sh2);
+  drop(c, h1);
+  if (own_sc) drop(c, sc);
+  return 0;
+}
+
+// softmax(Q K^T * scale) V over T tokens; qkv is [B][T][3C] (q|k|v, or per-head [q,k,v] blocks)
+int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scale, float* out /*[B][T][C]*/) {
+  const int Dh = C / heads;
+  float* Sbuf = nullptr;
+  TRY(c.e->pool.get((size_t)c.B * heads * T * T, &Sbuf));
+  const long long img = (long long)T * 3 * C;
+  const int q_off = 0, k_off = (heads == 1) ? C : Dh, v_off = (heads == 1) ? 2 * C : 2 * Dh;
+  const long long head_stride = (heads == 1) ? 0 : 3 * Dh;
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = qkv + q_off; g.c0 = Dh; g.lda0 = 3 * C; g.a0_zo = img; g.a0_zi = head_stride;
+  g.Hin = T; g.Win = 1; g.Hout = T; g.Wout = 1;
+  g.Cin = Dh; g.Cout = T; g.ks = 1; g.stride = 1;
+  g.w = qkv + k_off; g.ldb = 3 * C; g.bT = 1; g.w_zo = img; g.w_zi = head_stride;
+  g.alpha = scale;
+  g.out = Sbuf; g.ldo = T; g.o_zo = (long long)heads * T * T; g.o_zi = (long long)T * T;
+  g.ZI = heads; g.Z = c.B * heads;
+  TRY(run_gemm(c, g));
+  HIPCHK(launch_softmax_rows(Sbuf, (long long)c.B * heads * T, T, c.s));
+  memset(&g, 0, sizeof g);
+  g.a0 = Sbuf; g.c0 = T; g.lda0 = T; g.a0_zo = (long long)heads * T * T; g.a0_zi = (long long)T * T;
+  g.Hin = T; g.Win = 1; g.Hout = T; g.Wout = 1;
+  g.Cin = T; g.Cout = Dh; g.ks = 1; g.stride = 1;
+  g.w = qkv + v_off; g.ldb = 3 * C; g.bT = 0; g.w_zo = img; g.w_zi = head_stride;
+  g.alpha = 1.0f;
+  g.out = out; g.ldo = C; g.o_zo = (long long)T * C; g.o_zi = Dh;
+  g.ZI = heads; g.Z = c.B * heads;
+  TRY(run_gemm(c, g));
+  c.e->pool.put(Sbuf);
+  return 0;
+}
+
+// AttnBlock (models/ddpm/diffusion.py:200-225): GN -> fused q|k|v 1x1 -> attention -> proj_out -> + x
+int attnblock(Ctx& c, const std::string& p, const Act& x, Act* out) {
+  float *sc, *sh;
+  TRY(gn(c, x, nullptr, p + ".norm", 1e-6f, &sc, &sh));
+  Act qkv;
+  TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  Act o;
+  TRY(new_act(c, x.C, x.H, x.W, &o));
+  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, 1, 1.0f / std::sqrt((float)x.C), o.p));
+  drop(c, qkv);
+  TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr,
+           &x, out));
+  drop(c, o);
+  return 0;
+}
+
+// DeltaBlock (models/ddpm/diffusion.py:250-263)
+int deltablock(Ctx& c, const std::string& p, const Act& h, bool use_temb, Act* out) {
+  Act d1;
+  TRY(conv(c, h, nullptr, p + ".conv1.weight", p + ".conv1.bias", h.C, 1, 1, 0, nullptr, nullptr, 0,
+           use_temb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1));
+  float *sc, *sh;
+  TRY(gn(c, d1, nullptr, p + ".norm2", 1e-6f, &sc, &sh));
+  TRY(conv(c, d1, nullptr, p + ".conv2.weight", p + ".conv2.bias", h.C, 1, 1, 0, sc, sh, 1, nullptr, nullptr, out));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  drop(c, d1);
+  return 0;
+}
+
+int decoder(Ctx& c, const Act& hin, const std::vector<Act>& skips, Act* eps) {
+  const asyrp_config& cf = c.e->cfg;
+  const int L = cf.n_levels;
+  int res = cf.resolution >> (L - 1);
+  int k = (int)skips.size() - 1;
+  Act h = hin;
+  bool own = false;
+  auto replace = [&](Act& nh) {
+    if (own) drop(c, h);
+    h = nh;
+    own = true;
+  };
+  for (int i = L - 1; i >= 0; --i) {
+    for (int j = 0; j < cf.num_res_blocks + 1; ++j) {
+      Act o;
+      TRY(resblock(c, S("up.%d.block.%d", i, j), h, &skips[k], &o));
+      --k;
+      replace(o);
+      if (has_attn(cf, res)) {
+        Act o2;
+        TRY(attnblock(c, S("up.%d.attn.%d", i, j), h, &o2));
+        replace(o2);
+      }
+    }
+    if (i != 0) {
+      Act o;
+      TRY(conv(c, h, nullptr, S("up.%d.upsample.conv.weight", i), S("up.%d.upsample.conv.bias", i), h.C, 3, 1, 1,
+               nullptr, nullptr, 0, nullptr, nullptr, &o));
+      replace(o);
+      res *= 2;
+    }
+  }
+  float *sc, *sh;
+  TRY(gn(c, h, nullptr, "norm_out", 1e-6f, &sc, &sh));
+  TRY(conv(c, h, nullptr, "conv_out.weight", "conv_out.bias", cf.out_channels, 3, 1, 0, sc, sh, 1, nullptr, nullptr,
+           eps));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  if (own) drop(c, h);
+  return 0;
+}
+
+// DDPM.forward (models/ddpm/diffusion.py:473-580) on NHWC buffers.  Outputs are pool buffers (NHWC) the
+// caller drops.  et_mod.p == nullptr when no second decoder ran (index<0, or index>=0 without edit: ε̃ ≡ ε).
+int unet_core(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int apply_edit, const float* coeff,
+              int ignore_t, Act* et, Act* et_mod, Act* last_delta, Act* middle) {
+  asyrp_engine* e = c.e;
+  const asyrp_config& cf = e->cfg;
+  const int L = cf.n_levels, R = cf.resolution;
+  et_mod->p = nullptr;
+  last_delta->p = nullptr;
+  // timestep embedding + every block's Linear(swish(temb)) in one launch
+  float *temb, *temb_act;
+  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
+  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
+  TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
+  HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 1, P(c, "temb.dense.0.weight"), P(c, "temb.dense.0.bias"),
+                         P(c, "temb.dense.1.weight"), P(c, "temb.dense.1.bias"), cf.ch, e->temb_ch, temb, temb_act,
+                         c.B, c.s));
+  HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
+                            e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  e->pool.put(temb);
+  e->pool.put(temb_act);
+
+  // encoder (:485-495)
+  std::vector<Act> skips;
+  Act xin;
+  xin.p = const_cast<float*>(x_nhwc); xin.C = cf.in_channels; xin.H = R; xin.W = R;
+  {
+    Act h0;
+    TRY(conv(c, xin, nullptr, "conv_in.weight", "conv_in.bias", cf.ch, 3, 1, 0, nullptr, nullptr, 0, nullptr, nullptr,
+             &h0));
+    skips.push_back(h0);
+  }
+  int res = R;
+  for (int i = 0; i < L; ++i) {
+    for (int j = 0; j < cf.num_res_blocks; ++j) {
+      Act o;
+      TRY(resblock(c, S("down.%d.block.%d", i, j), skips.back(), nullptr, &o));
+      if (has_attn(cf, res)) {
+        Act o2;
+        TRY(attnblock(c, S("down.%d.attn.%d", i, j), o, &o2));
+        drop(c, o);
+        o = o2;
+      }
+      skips.push_back(o);
+    }
+    if (i != L - 1) {
+      Act o;
+      TRY(conv(c, skips.back(), nullptr, S("down.%d.downsample.conv.weight", i), S("down.%d.downsample.conv.bias", i),
+               skips.back().C, 3, 2, 0, nullptr, nullptr, 0, nullptr, nullptr, &o));
+      skips.push_back(o);
+      res /= 2;
+    }
+  }
+  // middle (:500-504)
+  Act m1, m2, h;
+  TRY(resblock(c, "mid.block_1", skips.back(), nullptr, &m1));
+  TRY(attnblock(c, "mid.attn_1", m1, &m2));
+  drop(c, m1);
+  TRY(resblock(c, "mid.block_2", m2, nullptr, &h));
+  drop(c, m2);
+  *middle = h;
+
+  if (index >= 0 && apply_edit) {   // :510-516
+    std::vector<Act> deltas(index + 1);
+    const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
+    for (int i = 0; i <= index; ++i) {
+      TRY(deltablock(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
+      dptr[i] = deltas[i].p;
+    }
+    Act h2;
+    TRY(new_act(c, h.C, h.H, h.W, &h2));
+    HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
+    for (int i = 0; i < index; ++i) drop(c, deltas[i]);
+    *last_delta = deltas[index];
+    TRY(decoder(c, h2, skips, et_mod));
+    drop(c, h2);
+  }
+  TRY(decoder(c, h, skips, et));
+  for (auto& a : skips) drop(c, a);
+  e->pool.put(c.tproj);
+  c.tproj = nullptr;
+  return 0;
+}
+
+__global__ void fill_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+int check_ready(asyrp_engine* e, int B) {
+  if (!e) return fail(ASYRP_EINVAL, "null engine");
+  if (!e->finalized) return fail(ASYRP_ESTATE, "asyrp_finalize_params has not been called");
+  if (B < 1 || B > e->max_batch) return fail(ASYRP_EINVAL, "batch size outside [1, max_batch]");
+  if (!e->d_freqs) return fail(ASYRP_ESTATE, "asyrp_set_temb_freqs has not been called");
+  return 0;
+}
+
+int ddim_apply(Ctx& c, const float* x, const Act& et, const Act& et_mod, const float* noise_nhwc, int t, int t_next,
+               float eta, float dt_lambda, int dt_end, float* xn, float* x0t) {
+  asyrp_engine* e = c.e;
+  if (e->alphas.empty()) return fail(ASYRP_ESTATE, "asyrp_set_schedule has not been called");
+  if (t < 0 || t >= (int)e->alphas.size() || t_next >= (int)e->alphas.size())
+    return fail(ASYRP_EINVAL, "timestep outside the schedule");
+  if (eta != 0.f && !noise_nhwc) return fail(ASYRP_EINVAL, "eta != 0 requires a noise tensor");
+  DdimArgs a;
+  memset(&a, 0, sizeof a);
+  a.xt = x; a.et = et.p; a.et_mod = et_mod.p; a.ld_e = et.C;
+  a.noise = noise_nhwc;
+  a.at = e->alphas[t];
+  a.at_next = (t_next < 0) ? 1.0f : e->alphas[t_next];   // utils/diffusion_utils.py:68-69
+  a.eta = eta; a.dt_lambda = dt_lambda;
+  a.apply_dt = (dt_lambda != 1.0f && t >= dt_end) ? 1 : 0;   // :99
+  a.xt_next = xn; a.x0_t = x0t;
+  a.npix = (long long)c.B * et.H * et.W;
+  HIPCHK(launch_ddim(a, c.s));
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int asyrp_abi_version(void) { return 1; }
+
+const char* asyrp_last_error(void) { return g_err.c_str(); }
+
+int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int device) {
+  if (!out || !cfg) return fail(ASYRP_EINVAL, "null argument");
+  if (cfg->family != ASYRP_FAMILY_DDPM) return fail(ASYRP_EINVAL, "only the DDPM family is implemented in this build");
+  if (cfg->n_levels < 1 || cfg->n_levels > ASYRP_MAX_LEVELS || cfg->ch % 32 != 0 || max_batch < 1 || cfg->n_delta < 0 ||
+      cfg->n_delta > 4 || cfg->resolution % (1 << (cfg->n_levels - 1)) != 0)
+    return fail(ASYRP_EINVAL, "unsupported configuration");
+  // no device call here: the engine can be created (and its parameter inventory listed) without a GPU;
+  // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
+  asyrp_engine* e = new asyrp_engine();
+  e->cfg = *cfg;
+  e->max_batch = max_batch;
+  e->device = device;
+  build_specs_ddpm(e);
+  for (size_t i = 0; i < e->specs.size(); ++i) e->spec_idx[e->specs[i].key] = (int)i;
+  e->host.resize(e->specs.size());
+  e->loaded.assign(e->specs.size(), 0);
+  *out = e;
+  return 0;
+}
+
+void asyrp_destroy(asyrp_engine* e) {
+  if (!e) return;
+  if (e->finalized || e->d_freqs || !e->dev.empty()) {
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+  }
+  for (auto& kv : e->dev) (void)hipFree(kv.second);
+  if (e->d_freqs) (void)hipFree(e->d_freqs);
+  if (e->d_t) (void)hipFree(e->d_t);
+  for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  e->pool.destroy();
+  delete e;
+}
+
+int asyrp_num_params(const asyrp_engine* e) { return e ? (int)e->specs.size() : 0; }
+
+int asyrp_param_info(const asyrp_engine* e, int i, const char** key, int64_t shape[4], int* ndim) {
+  if (!e || i < 0 || i >= (int)e->specs.size()) return fail(ASYRP_EINVAL, "param index out of range");
+  const ParamSpec& s = e->specs[i];
+  if (key) *key = s.key.c_str();
+  if (ndim) *ndim = (int)s.shape.size();
+  if (shape)
+    for (size_t d = 0; d < 4; ++d) shape[d] = d < s.shape.size() ? s.shape[d] : 1;
+  return 0;
+}
+
+int asyrp_load_param(asyrp_engine* e, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+  if (!e || !key || !host_data || !shape) return fail(ASYRP_EINVAL, "null argument");
+  auto it = e->spec_idx.find(key);
+  if (it == e->spec_idx.end()) return fail(ASYRP_EKEY, std::string("unexpected parameter key: ") + key);
+  const ParamSpec& s = e->specs[it->second];
+  if ((int)s.shape.size() != ndim) return fail(ASYRP_EKEY, std::string("rank mismatch for ") + key);
+  for (int d = 0; d < ndim; ++d)
+    if (s.shape[d] != shape[d]) return fail(ASYRP_EKEY, std::string("shape mismatch for ") + key);
+  e->host[it->second].assign(host_data, host_data + s.numel());
+  e->loaded[it->second] = 1;
+  e->finalized = false;
+  return 0;
+}
+
+int asyrp_set_schedule(asyrp_engine* e, const float* ab, int n) {
+  if (!e || !ab || n < 1) return fail(ASYRP_EINVAL, "bad schedule");
+  e->alphas.assign(ab, ab + n);
+  return 0;
+}
+
+int asyrp_set_temb_freqs(asyrp_engine* e, const float* f, int n) {
+  if (!e || !f || n != e->cfg.ch / 2) return fail(ASYRP_EINVAL, "freqs must have ch/2 entries");
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->d_freqs) HIPCHK(hipMalloc(&e->d_freqs, sizeof(float) * n));
+  HIPCHK(hipMemcpy(e->d_freqs, f, sizeof(float) * n, hipMemcpyHostToDevice));
+  e->n_freqs = n;
+  return 0;
+}
+
+int asyrp_finalize_params(asyrp_engine* e) {
+  if (!e) return fail(ASYRP_EINVAL, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  for (size_t i = 0; i < e->specs.size(); ++i)
+    if (!e->loaded[i]) return fail(ASYRP_EKEY, "parameter not loaded: " + e->specs[i].key);
+  HIPCHK(hipDeviceSynchronize());
+  if (!e->d_t) HIPCHK(hipMalloc(&e->d_t, sizeof(float) * e->max_batch));
+  // temb projections of every ResnetBlock / DeltaBlock -> one [O_total][temb_ch] matrix
+  std::vector<float> tw, tb;
+  e->tproj_off.clear();
+  int off = 0;
+  for (auto& s : e->specs) {
+    if (!ends_with(s.key, ".temb_proj.weight")) continue;
+    const std::string p = s.key.substr(0, s.key.size() - strlen(".temb_proj.weight"));
+    const auto& w = hostp(e, s.key);
+    const auto& b = hostp(e, p + ".temb_proj.bias");
+    e->tproj_off[p] = off;
+    tw.insert(tw.end(), w.begin(), w.end());
+    tb.insert(tb.end(), b.begin(), b.end());
+    off += (int)s.shape[0];
+  }
+  e->tproj_total = off;
+  TRY(upload(e, "__tproj.weight", tw));
+  TRY(upload(e, "__tproj.bias", tb));
+  for (auto& s : e->specs) {
+    const auto& v = hostp(e, s.key);
+    if (ends_with(s.key, ".temb_proj.weight") || ends_with(s.key, ".temb_proj.bias")) continue;
+    if (s.shape.size() == 4) {
+      const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (int)s.shape[2];
+      const std::string p = s.key.substr(0, s.key.size() - strlen(".weight"));
+      if (ends_with(p, ".q")) {   // fuse q|k|v into one [Cin][3C] operand
+        const std::string ap = p.substr(0, p.size() - 2);
+        std::vector<float> w((size_t)cin * 3 * cout), b((size_t)3 * cout);
+        const char* names[3] = {".q", ".k", ".v"};
+        for (int t = 0; t < 3; ++t) {
+          const auto& wt = hostp(e, ap + names[t] + ".weight");
+          const auto& bt = hostp(e, ap + names[t] + ".bias");
+          for (int co = 0; co < cout; ++co) {
+            for (int ci = 0; ci < cin; ++ci) w[(size_t)ci * 3 * cout + t * cout + co] = wt[(size_t)co * cin + ci];
+            b[(size_t)t * cout + co] = bt[co];
+          }
+        }
+        TRY(upload(e, ap + ".qkv.weight", w));
+        TRY(upload(e, ap + ".qkv.bias", b));
+      } else if (ends_with(p, ".k") || ends_with(p, ".v")) {
+        continue;
+      } else {
+        TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
+      }
+    } else {
+      const std::string p = s.key.substr(0, s.key.rfind('.'));
+      if (ends_with(p, ".q") || ends_with(p, ".k") || ends_with(p, ".v")) continue;   // folded into qkv.bias
+      TRY(upload(e, s.key, v));
+    }
+  }
+  e->finalized = true;
+  return 0;
+}
+
+int64_t asyrp_device_bytes(const asyrp_engine* e) { return e ? (int64_t)(e->param_bytes + e->pool.total_bytes) : 0; }
+
+int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, int index, int apply_edit,
+                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* et, float* et_mod,
+                       float* delta_h_out, float* middle_h, void* stream) {
+  TRY(check_ready(e, B));
+  if (!x || !t || !et) return fail(ASYRP_EINVAL, "null tensor");
+  if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
+  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < index + 2))
+    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  if (index >= 0 && !et_mod) return fail(ASYRP_EINVAL, "et_mod buffer required when index is given");
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  const asyrp_config& cf = e->cfg;
+  const int HW = cf.resolution * cf.resolution;
+  float* xn = nullptr;
+  TRY(e->pool.get((size_t)B * HW * cf.in_channels, &xn));
+  HIPCHK(launch_nchw_to_nhwc(x, xn, B, cf.in_channels, HW, c.s));
+  Act a_et, a_em, a_dh, a_mid;
+  TRY(unet_core(c, xn, t, index, apply_edit, hs_coeff_host, ignore_timestep, &a_et, &a_em, &a_dh, &a_mid));
+  HIPCHK(launch_nhwc_to_nchw(a_et.p, a_et.C, et, B, a_et.C, HW, c.s));
+  if (index >= 0) {
+    const Act& src = a_em.p ? a_em : a_et;   // no edit: ε̃ ≡ ε
+    HIPCHK(launch_nhwc_to_nchw(src.p, src.C, et_mod, B, src.C, HW, c.s));
+  }
+  if (a_dh.p && delta_h_out) HIPCHK(launch_nhwc_to_nchw(a_dh.p, a_dh.C, delta_h_out, B, a_dh.C, a_dh.H * a_dh.W, c.s));
+  if (middle_h) HIPCHK(launch_nhwc_to_nchw(a_mid.p, a_mid.C, middle_h, B, a_mid.C, a_mid.H * a_mid.W, c.s));
+  drop(c, a_et);
+  if (a_em.p) drop(c, a_em);
+  if (a_dh.p) drop(c, a_dh);
+  drop(c, a_mid);
+  e->pool.put(xn);
+  return 0;
+}
+
+int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, float eta, const float* noise,
+                    int learn_sigma, int index, int apply_edit, const float* hs_coeff_host, int n_coeff,
+                    int ignore_timestep, float dt_lambda, int dt_end, float* xt_next, float* x0_t,
+                    float* delta_h_out, float* middle_h, void* stream) {
+  TRY(check_ready(e, B));
+  if (!xt || !xt_next) return fail(ASYRP_EINVAL, "null tensor");
+  if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
+  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < index + 2))
+    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  const asyrp_config& cf = e->cfg;
+  if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
+    return fail(ASYRP_EINVAL, "DDIM step expects 3 image channels");
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  const int HW = cf.resolution * cf.resolution;
+  float *xn, *xo, *x0o, *nz = nullptr;
+  TRY(e->pool.get((size_t)B * HW * 3, &xn));
+  TRY(e->pool.get((size_t)B * HW * 3, &xo));
+  TRY(e->pool.get((size_t)B * HW * 3, &x0o));
+  HIPCHK(launch_nchw_to_nhwc(xt, xn, B, 3, HW, c.s));
+  if (eta != 0.f) {
+    if (!noise) return fail(ASYRP_EINVAL, "eta != 0 requires a noise tensor");
+    TRY(e->pool.get((size_t)B * HW * 3, &nz));
+    HIPCHK(launch_nchw_to_nhwc(noise, nz, B, 3, HW, c.s));
+  }
+  hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+  Act a_et, a_em, a_dh, a_mid;
+  TRY(unet_core(c, xn, e->d_t, index, apply_edit, hs_coeff_host, ignore_timestep, &a_et, &a_em, &a_dh, &a_mid));
+  TRY(ddim_apply(c, xn, a_et, a_em, nz, t, t_next, eta, dt_lambda, dt_end, xo, x0o));
+  HIPCHK(launch_nhwc_to_nchw(xo, 3, xt_next, B, 3, HW, c.s));
+  if (x0_t) HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0_t, B, 3, HW, c.s));
+  if (a_dh.p && delta_h_out) HIPCHK(launch_nhwc_to_nchw(a_dh.p, a_dh.C, delta_h_out, B, a_dh.C, a_dh.H * a_dh.W, c.s));
+  if (middle_h) HIPCHK(launch_nhwc_to_nchw(a_mid.p, a_mid.C, middle_h, B, a_mid.C, a_mid.H * a_mid.W, c.s));
+  drop(c, a_et);
+  if (a_em.p) drop(c, a_em);
+  if (a_dh.p) drop(c, a_dh);
+  drop(c, a_mid);
+  e->pool.put(xn); e->pool.put(xo); e->pool.put(x0o);
+  if (nz) e->pool.put(nz);
+  return 0;
+}
+
+int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv, int n_inv, const int32_t* seq_gen,
+                   int n_gen, int t_edit, int t_addnoise, int index, const float* hs_coeff_host, int n_coeff,
+                   int learn_sigma, const float* noise, int n_noise, float* x_T, float* x_edit, void* stream) {
+  TRY(check_ready(e, B));
+  if (!x0 || !x_edit || n_gen < 1 || !seq_gen || (n_inv > 0 && !seq_inv)) return fail(ASYRP_EINVAL, "bad argument");
+  if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
+  if (index >= 0 && (!hs_coeff_host || n_coeff < index + 2)) return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  const asyrp_config& cf = e->cfg;
+  if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
+    return fail(ASYRP_EINVAL, "edit loop expects 3 image channels");
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  const int HW = cf.resolution * cf.resolution;
+  const size_t nx = (size_t)B * HW * 3;
+  float *xa, *xb, *nz = nullptr;
+  TRY(e->pool.get(nx, &xa));
+  TRY(e->pool.get(nx, &xb));
+  HIPCHK(launch_nchw_to_nhwc(x0, xa, B, 3, HW, c.s));
+  // loop A — DDIM inversion (diffusion_latent.py:1034-1045): (t, t_next) = (seq[k-1], seq[k]), k = 1..n_inv-1
+  for (int k = 1; k < n_inv; ++k) {
+    const int t = seq_inv[k - 1], tn = seq_inv[k];
+    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    Act a_et, a_em, a_dh, a_mid;
+    TRY(unet_core(c, xa, e->d_t, -1, 0, nullptr, 0, &a_et, &a_em, &a_dh, &a_mid));
+    TRY(ddim_apply(c, xa, a_et, a_em, nullptr, t, tn, 0.f, 1.f, 999, xb, nullptr));
+    drop(c, a_et);
+    drop(c, a_mid);
+    std::swap(xa, xb);
+  }
+  if (x_T) HIPCHK(launch_nhwc_to_nchw(xa, 3, x_T, B, 3, HW, c.s));
+  // loop B — Asyrp generation (diffusion_latent.py:503-520): t descending, last t_next = -1
+  int used_noise = 0;
+  for (int k = n_gen - 1; k >= 0; --k) {
+    const int t = seq_gen[k], tn = (k > 0) ? seq_gen[k - 1] : -1;
+    const int edit = (index >= 0 && t >= t_edit) ? 1 : 0;
+    const float eta = (t < t_addnoise) ? 1.0f : 0.0f;
+    const float* nzp = nullptr;
+    if (eta != 0.f) {
+      if (!noise || used_noise >= n_noise) return fail(ASYRP_EINVAL, "not enough noise tensors for the eta=1 steps");
+      if (!nz) TRY(e->pool.get(nx, &nz));
+      HIPCHK(launch_nchw_to_nhwc(noise + (size_t)used_noise * nx, nz, B, 3, HW, c.s));
+      ++used_noise;
+      nzp = nz;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    Act a_et, a_em, a_dh, a_mid;
+    TRY(unet_core(c, xa, e->d_t, index, edit, hs_coeff_host, 0, &a_et, &a_em, &a_dh, &a_mid));
+    TRY(ddim_apply(c, xa, a_et, a_em, nzp, t, tn, eta, 1.f, 999, xb, nullptr));
+    drop(c, a_et);
+    if (a_em.p) drop(c, a_em);
+    if (a_dh.p) drop(c, a_dh);
+    drop(c, a_mid);
+    std::swap(xa, xb);
+  }
+  HIPCHK(launch_nhwc_to_nchw(xa, 3, x_edit, B, 3, HW, c.s));
+  e->pool.put(xa); e->pool.put(xb);
+  if (nz) e->pool.put(nz);
+  return 0;
+}
+
+int asyrp_profile_enable(asyrp_engine* e, int on) {
+  if (!e) return fail(ASYRP_EINVAL, "null engine");
+  e->prof_on = on != 0;
+  return 0;
+}
+
+int asyrp_profile_read(asyrp_engine* e, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                       double* conv_bytes) {
+  if (!e) return fail(ASYRP_EINVAL, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  // dominant family = 3x3 stride-1 implicit-GEMM conv (variant 310)
+  double ms = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (auto& r : e->prof) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+    if (r.variant == 310) { ms += t; fl += r.flops; by += r.bytes; ++n; }
+    e->ev_free.emplace_back(r.a, r.b);
+  }
+  e->prof.clear();
+  if (conv_ms) *conv_ms = ms;
+  if (conv_launches) *conv_launches = n;
+  if (conv_flops) *conv_flops = fl;
+  if (conv_bytes) *conv_bytes = by;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// op-level test hooks (synchronous; allocate scratch with hipMalloc)
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* src, float* dst, int cout, int cin, int kk) {
+  const long long total = (long long)cout * cin * kk;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % kk);
+    const long long r = i / kk;
+    const int ci = (int)(r % cin), co = (int)(r / cin);
+    dst[((long long)t * cin + ci) * cout + co] = src[i];
+  }
+}
+
+int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                    const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
+                    const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,
+                    const float* residual, float* y, void* stream) {
+  if (!x0 || !weight || !y || B < 1) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C0 + (x1 ? C1 : 0), HW = H * W;
+  int Ho = H, Wo = W;
+  if (upsample) { Ho *= 2; Wo *= 2; }
+  if (stride == 2) { Ho /= 2; Wo /= 2; }
+  std::vector<void*> tmp;
+  auto dalloc = [&](size_t nfloats, float** p) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(nfloats, 1) * sizeof(float)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  float *a0, *a1 = nullptr, *wp, *yo, *rs = nullptr, *sc = nullptr, *sh = nullptr;
+  TRY(dalloc((size_t)B * HW * C0, &a0));
+  HIPCHK(launch_nchw_to_nhwc(x0, a0, B, C0, HW, s));
+  if (x1) {
+    TRY(dalloc((size_t)B * HW * C1, &a1));
+    HIPCHK(launch_nchw_to_nhwc(x1, a1, B, C1, HW, s));
+  }
+  TRY(dalloc((size_t)ksize * ksize * Cin * Cout, &wp));
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(256), dim3(256), 0, s, weight, wp, Cout, Cin, ksize * ksize);
+  TRY(dalloc((size_t)B * Ho * Wo * Cout, &yo));
+  if (residual) {
+    TRY(dalloc((size_t)B * Ho * Wo * Cout, &rs));
+    HIPCHK(launch_nchw_to_nhwc(residual, rs, B, Cout, Ho * Wo, s));
+  }
+  if (gn_weight) {
+    float* part;
+    TRY(dalloc((size_t)B * Cin, &sc));
+    TRY(dalloc((size_t)B * Cin, &sh));
+    TRY(dalloc(gn_partial_doubles(B, Cin, HW) * 2, &part));
+    GnArgs a;
+    memset(&a, 0, sizeof a);
+    a.a0 = a0; a.c0 = C0; a.lda0 = C0; a.a0_z = (long long)HW * C0;
+    if (x1) { a.a1 = a1; a.c1 = C1; a.lda1 = C1; a.a1_z = (long long)HW * C1; }
+    a.HW = HW; a.N = B; a.C = Cin; a.gamma = gn_weight; a.beta = gn_bias; a.eps = gn_eps;
+    a.scale = sc; a.shift = sh; a.partial = reinterpret_cast<double*>(part);
+    HIPCHK(launch_gn(a, s));
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = a0; g.c0 = C0; g.lda0 = C0; g.a0_zo = (long long)HW * C0;
+  if (x1) { g.a1 = a1; g.c1 = C1; g.lda1 = C1; g.a1_zo = (long long)HW * C1; }
+  g.Hin = H; g.Win = W; g.Hout = Ho; g.Wout = Wo; g.Cin = Cin; g.Cout = Cout;
+  g.ks = ksize; g.stride = stride; g.ups = upsample; g.pad = (ksize == 3 && stride == 1) ? 1 : 0;
+  g.pscale = sc; g.pshift = sh; g.silu = silu;
+  g.w = wp; g.ldb = Cout; g.bias = bias;
+  g.chan_add = chan_add; g.ld_chan_add = Cout;
+  if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
+  g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
+  hipError_t le = launch_gemm(g, s);
+  if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);
+  hipError_t se = hipStreamSynchronize(s);
+  for (void* p : tmp) (void)hipFree(p);
+  if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv launch: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv sync: ") + hipGetErrorString(se));
+  return 0;
+}
+
+int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream) {
+  if (!qkv || !out || B < 1 || heads < 1 || C % heads) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  asyrp_engine tmp_e;   // only the pool is used
+  Ctx c{&tmp_e, s, B};
+  float *q2 = nullptr, *o2 = nullptr;
+  int rc = tmp_e.pool.get((size_t)B * T * 3 * C, &q2);
+  if (!rc) rc = tmp_e.pool.get((size_t)B * T * C, &o2);
+  hipError_t le = hipSuccess;
+  if (!rc) {
+    le = launch_nchw_to_nhwc(qkv, q2, B, 3 * C, T, s);
+    const int Dh = C / heads;
+    if (le == hipSuccess) rc = attention_core(c, q2, C, T, heads, 1.0f / std::sqrt((float)Dh), o2);
+    if (!rc && le == hipSuccess) le = launch_nhwc_to_nchw(o2, C, out, B, C, T, s);
+  }
+  hipError_t se = hipStreamSynchronize(s);
+  tmp_e.pool.destroy();
+  if (rc) return rc;
+  if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("attention launch: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("attention sync: ") + hipGetErrorString(se));
+  return 0;
+}
+
+}  // extern "C"

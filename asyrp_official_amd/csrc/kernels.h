@@ -1,0 +1,82 @@
+// kernels.h — launch interface of the gfx950 kernels (internal; the public ABI is include/asyrp.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asyrp {
+
+// One implicit-GEMM launch: out[z][m][n] = alpha * sum_k A[z][m][k] * B[(z)][k][n] (+bias +chan_add +resid)
+//   A = activations, NHWC, up to two channel-concatenated sources, optional per-(image,channel)
+//       affine (GroupNorm apply / FiLM) + SiLU prologue, optional nearest-x2 upsample, 3x3 halo via LDS.
+//   B = weights [ks*ks][Cin][ldb] (or, bT: B[k][n] = Bt[n][k], row stride ldb) optionally per-z.
+//   z = zo*ZI + zi  (zo = image, zi = attention head); all z-offsets are in floats.
+struct GemmArgs {
+  const float* a0; const float* a1;
+  int c0, c1, lda0, lda1;
+  long long a0_zo, a0_zi, a1_zo, a1_zi;
+  int Hin, Win, Hout, Wout;       // Hin/Win: source dims BEFORE upsample
+  int Cin, Cout;
+  int ks, stride, pad, ups;
+  const float* pscale; const float* pshift;  // [zo][Cin] or null
+  int silu;
+  const float* w; int ldb; int bT; long long w_zo, w_zi;
+  const float* bias;              // [Cout] or null
+  const float* chan_add; int ld_chan_add;   // [zo][ld] or null
+  const float* resid; int ldr; long long r_zo, r_zi;
+  float alpha;
+  float* out; int ldo; long long o_zo, o_zi;
+  int ZI, Z;
+  int tile;                       // 0 = auto, else TILE_* id
+};
+
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// algorithmic work of one launch (2*M*N*K flops; A read once + out written once + weights once)
+void gemm_work(const GemmArgs& a, double* flops, double* bytes);
+
+// GroupNorm(32) statistics of an NHWC tensor (two concatenated sources allowed) -> per-(image,channel)
+// scale/shift so that y = x*scale + shift == GN(x)*gamma+beta; optional FiLM (scale,shift) folding:
+// y = GN(x)*(1+fs)+fsh.  `partial` is scratch of gn_partial_floats() floats (holds doubles).
+struct GnArgs {
+  const float* a0; const float* a1;
+  int c0, c1, lda0, lda1;
+  long long a0_z, a1_z;
+  int HW, N, C;
+  const float* gamma; const float* beta; float eps;
+  const float* film_scale; const float* film_shift; int ld_film;   // [N][ld] or null
+  float* scale; float* shift;     // [N][C]
+  double* partial;
+};
+size_t gn_partial_doubles(int N, int C, int HW);
+hipError_t launch_gn(const GnArgs& a, hipStream_t s);
+
+hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s);
+
+// temb = dense1(swish(dense0(sinusoid(t)))) ; sin_first: DDPM [sin|cos] vs iDDPM [cos|sin]
+hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin_first, const float* w0,
+                           const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
+                           float* temb_act /* swish(temb) */, int B, hipStream_t s);
+// out[b][o] = sum_i W[o][i]*x[b][i] + bias[o]   (all per-block temb projections in one launch)
+hipError_t launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, int I, int O, float* out,
+                              int ldo, int B, hipStream_t s);
+
+// h2 = c0*h + sum_i c_{i+1} * d_i      (n_d <= 4), elementwise over `n` floats
+hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2,
+                      long long n, hipStream_t s);
+
+// NCHW <-> NHWC
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, int lds, float* dst, int N, int C, int HW, hipStream_t s);
+
+// DDIM update on NHWC(3) tensors, arithmetic order of utils/diffusion_utils.py:84-100
+struct DdimArgs {
+  const float* xt; const float* et; const float* et_mod; int ld_e;   // et: [N][HW][ld_e], first 3 channels used
+  const float* noise;             // NHWC(3) or null
+  float at, at_next, eta, dt_lambda; int apply_dt;
+  float* xt_next; float* x0_t;    // x0_t nullable
+  long long npix;                 // N*HW
+};
+hipError_t launch_ddim(const DdimArgs& a, hipStream_t s);
+
+}  // namespace asyrp

@@ -1,0 +1,722 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Asyrp DDIM sampling engine.
+//
+// Dominant kernel: igemm_f32 — implicit-GEMM convolution / GEMM on the fp32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 157 TFLOP/s chip peak), NHWC activations,
+// halo tile staged once in LDS and re-used by all 9 taps, GroupNorm-apply + SiLU fused into the
+// staging pass (prologue), bias + timestep projection + residual fused into the store (epilogue).
+// Reference ops it replaces: models/ddpm/diffusion.py:151-170 (ResnetBlock), :72-110 (Up/Downsample),
+// :200-225 (AttnBlock 1x1 convs and both bmm), :250-263 (DeltaBlock).
+#include "kernels.h"
+
+#include <math.h>
+
+namespace asyrp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;         // input channels staged per K-chunk
+constexpr int ASTR = KC + 1;   // LDS pixel stride of the A tile in floats (odd -> conflict-free column reads)
+
+template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_>
+struct TileCfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, KS = KS_, STRIDE = STRIDE_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int PW = (KS == 1) ? BM : (BM >= 128 ? 16 : 8);   // output patch (KS=1: linear run of pixels)
+  static constexpr int PH = BM / PW;
+  static constexpr int TH = (PH - 1) * STRIDE + KS, TW = (PW - 1) * STRIDE + KS;   // input halo tile
+  static constexpr int NPIX = TH * TW;
+  static constexpr int A_TILE = ((NPIX * ASTR + 3) / 4) * 4;
+  static constexpr int B_TILE = KC * BN;
+  static constexpr int NA = (NPIX * 4 + NT - 1) / NT;       // float4 A loads per thread per chunk
+  static constexpr int NB = (KC * BN / 4 + NT - 1) / NT;    // float4 B loads per thread per (chunk,tap)
+  static constexpr int NTAPS = KS * KS;
+  static constexpr size_t SMEM = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
+};
+
+__device__ __forceinline__ float silu_f(float v) {
+  // x * sigmoid(x), sigmoid = 1/(1+exp(-x))  (models/ddpm/diffusion.py:63-65)
+  const float s = 1.0f / (1.0f + expf(-v));
+  return v * s;
+}
+
+template <class T>
+__global__ void __launch_bounds__(T::NT) igemm_f32_kernel(const GemmArgs p) {
+  constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, PW = T::PW, PH = T::PH, TW = T::TW;
+  constexpr int NPIX = T::NPIX, A_TILE = T::A_TILE, B_TILE = T::B_TILE, NA = T::NA, NB = T::NB, NTAPS = T::NTAPS;
+  (void)PH;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int z = blockIdx.z, zo = z / p.ZI, zi = z - zo * p.ZI;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = p.Hout * p.Wout;
+  int m0 = 0, oy0 = 0, ox0 = 0;
+  if (KS == 1) {
+    m0 = blockIdx.x * BM;
+  } else {
+    const int tiles_x = (p.Wout + PW - 1) / PW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    oy0 = ty * PH;
+    ox0 = tx * PW;
+  }
+  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo + (long long)zi * p.a0_zi;
+  const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo + (long long)zi * p.a1_zi : nullptr;
+  const float* __restrict__ wz = p.w + (long long)zo * p.w_zo + (long long)zi * p.w_zi;
+  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
+  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
+  const int Cin = p.Cin, Cout = p.Cout, c0 = p.c0;
+
+  // block-uniform vector-path flags
+  const bool avec = (((p.c0 | p.c1 | p.lda0 | p.lda1 | Cin) & 3) == 0) &&
+                    ((((uintptr_t)a0) | ((uintptr_t)a1)) & 15) == 0;
+  const bool bvec = ((p.ldb & 3) == 0) && ((((uintptr_t)wz) & 15) == 0) && (p.bT ? ((Cin & 3) == 0) : true);
+
+  // ---- per-thread A staging map (chunk independent) ----
+  const int aq = tid & 3;   // channel quad inside the chunk (NT % 4 == 0)
+  int aoff[NA];             // source pixel index, -1 = zero padding, -2 = outside the tile
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int pix = (tid + i * NT) >> 2;
+    int off = -2;
+    if (pix < NPIX) {
+      if (KS == 1) {
+        const int m = m0 + pix;
+        off = (m < HWo) ? m : -1;
+      } else {
+        const int iy = pix / TW, ix = pix - iy * TW;
+        const int gy = oy0 * STRIDE - p.pad + iy, gx = ox0 * STRIDE - p.pad + ix;
+        const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
+        off = (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
+      }
+    }
+    aoff[i] = off;
+  }
+
+  float4 areg[NA];
+  float4 breg[NB];
+
+  auto gload_A = [&](int chunk) {
+    const int c = chunk * KC + aq * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int sp = aoff[i];
+      if (sp >= 0 && c < Cin) {
+        if (avec) {
+          const float* src = (c < c0) ? (a0 + (long long)sp * p.lda0 + c) : (a1 + (long long)sp * p.lda1 + (c - c0));
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cc = c + j;
+            t[j] = (cc < Cin) ? ((cc < c0) ? a0[(long long)sp * p.lda0 + cc] : a1[(long long)sp * p.lda1 + (cc - c0)]) : 0.f;
+          }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      areg[i] = v;
+    }
+  };
+
+  auto write_A = [&](int chunk, int buf) {
+    const int c = chunk * KC + aq * 4;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ps) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < Cin) { sc[j] = ps[c + j]; sh[j] = psh[c + j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (aoff[i] == -2) continue;
+      float t[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+      if (aoff[i] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c + j < Cin) {
+            float v = t[j];
+            if (ps) v = v * sc[j] + sh[j];
+            if (p.silu) v = silu_f(v);
+            t[j] = v;
+          }
+        }
+      }
+      const int pix = (tid + i * NT) >> 2;
+      float* dst = As + buf * A_TILE + pix * ASTR + aq * 4;
+      dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+    }
+  };
+
+  auto gload_B = [&](int it) {
+    const int chunk = it / NTAPS, tap = it - chunk * NTAPS;
+    const int kb = chunk * KC;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < KC * BN / 4) {
+        if (!p.bT) {
+          const int k = e / (BN / 4), nq = e - k * (BN / 4);
+          const int n = n0 + nq * 4, kk = kb + k;
+          if (kk < Cin && n < Cout) {
+            const float* row = wz + (long long)(tap * Cin + kk) * p.ldb + n;
+            if (bvec && n + 3 < Cout) {
+              v = *reinterpret_cast<const float4*>(row);
+            } else {
+              v.x = row[0];
+              if (n + 1 < Cout) v.y = row[1];
+              if (n + 2 < Cout) v.z = row[2];
+              if (n + 3 < Cout) v.w = row[3];
+            }
+          }
+        } else {
+          const int nl = e >> 2, kq = e & 3;
+          const int n = n0 + nl, kk = kb + kq * 4;
+          if (n < Cout && kk < Cin) {
+            const float* row = wz + (long long)n * p.ldb + kk;
+            if (bvec && kk + 3 < Cin) {
+              v = *reinterpret_cast<const float4*>(row);
+            } else {
+              v.x = row[0];
+              if (kk + 1 < Cin) v.y = row[1];
+              if (kk + 2 < Cin) v.z = row[2];
+              if (kk + 3 < Cin) v.w = row[3];
+            }
+          }
+        }
+      }
+      breg[i] = v;
+    }
+  };
+
+  auto write_B = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * NT;
+      if (e < KC * BN / 4) {
+        if (!p.bT) {
+          const int k = e / (BN / 4), nq = e - k * (BN / 4);
+          *reinterpret_cast<float4*>(Bs + buf * B_TILE + k * BN + nq * 4) = breg[i];
+        } else {
+          const int nl = e >> 2, kq = e & 3;
+          float* dst = Bs + buf * B_TILE + (kq * 4) * BN + nl;
+          dst[0] = breg[i].x; dst[BN] = breg[i].y; dst[2 * BN] = breg[i].z; dst[3 * BN] = breg[i].w;
+        }
+      }
+    }
+  };
+
+  // ---- MFMA operand addressing (v_mfma_f32_32x32x2_f32: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]) ----
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = (wm * TM + tm) * 32 + (lane & 31);
+    int tp;
+    if (KS == 1) {
+      tp = m;
+    } else {
+      const int py = m / PW, px = m - py * PW;
+      tp = (py * STRIDE) * TW + px * STRIDE;
+    }
+    abase[tm] = tp * ASTR + (lane >> 5);
+  }
+  const int bbase = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nchunks = (Cin + KC - 1) / KC;
+  const int niter = nchunks * NTAPS;
+
+  // ---- prologue: stage chunk 0 / tap 0 ----
+  gload_A(0);
+  gload_B(0);
+  write_A(0, 0);
+  write_B(0);
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    const int chunk = it / NTAPS, tap = it - chunk * NTAPS;
+    const bool more = (it + 1 < niter);
+    const bool next_a = (tap == NTAPS - 1) && (chunk + 1 < nchunks);
+    if (more) gload_B(it + 1);
+    if (next_a) gload_A(chunk + 1);
+
+    {
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const float* A = As + (chunk & 1) * A_TILE + (ky * TW + kx) * ASTR;
+      const float* B = Bs + (it & 1) * B_TILE + bbase;
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = A[abase[tm] + 2 * kk];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = B[2 * kk * BN + tn * 32];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+
+    if (more) write_B((it + 1) & 1);
+    if (next_a) write_A(chunk + 1, (chunk + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo + (long long)zi * p.o_zi;
+  const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo + (long long)zi * p.r_zi : nullptr;
+  const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+    if (n >= Cout) continue;
+    float addn = 0.f;
+    const bool has_b = (p.bias != nullptr), has_c = (cadd != nullptr);
+    const float bn = has_b ? p.bias[n] : 0.f;
+    const float cn = has_c ? cadd[n] : 0.f;
+    (void)addn;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        long long pixel;
+        bool ok;
+        if (KS == 1) {
+          pixel = m0 + m;
+          ok = pixel < HWo;
+        } else {
+          const int oy = oy0 + m / PW, ox = ox0 + (m % PW);
+          ok = (oy < p.Hout) && (ox < p.Wout);
+          pixel = (long long)oy * p.Wout + ox;
+        }
+        if (ok) {
+          float v = acc[tm][tn][r] * p.alpha;
+          if (has_b) v = v + bn;
+          if (has_c) v = v + cn;
+          if (rz) v = v + rz[pixel * p.ldr + n];
+          outz[pixel * p.ldo + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+static hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
+  int gx;
+  if (T::KS == 1) {
+    gx = (a.Hout * a.Wout + T::BM - 1) / T::BM;
+  } else {
+    gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
+  }
+  const int gy = (a.Cout + T::BN - 1) / T::BN;
+  dim3 grid(gx, gy, a.Z), block(T::NT);
+  static bool attr_set = false;
+  if (!attr_set && T::SMEM > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(igemm_f32_kernel<T>, grid, block, T::SMEM, s, a);
+  return hipGetLastError();
+}
+
+static int auto_tile(const GemmArgs& a) {
+  if (a.stride == 2) return TILE_64x64;
+  if (a.Cout <= 32) return TILE_128x32;
+  const long long M = (long long)a.Hout * a.Wout;
+  auto blocks = [&](int bm, int bn) {
+    long long mt;
+    if (a.ks == 1) {
+      mt = (M + bm - 1) / bm;
+    } else {
+      const int ph = 8, pw = bm / 8;
+      mt = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
+    }
+    return mt * ((a.Cout + bn - 1) / bn) * a.Z;
+  };
+  // prefer the big tile when it still fills the 256 CUs about twice over; else shrink
+  if (a.Cout > 64 && M >= 128 && blocks(128, 128) >= 384) return TILE_128x128;
+  if (M >= 128 && blocks(128, 64) >= 384) return TILE_128x64;
+  if (M >= 128 && a.Cout > 64 && blocks(128, 128) >= blocks(64, 64) / 2 && blocks(128, 128) >= 256) return TILE_128x128;
+  return TILE_64x64;
+}
+
+hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+  GemmArgs a = a_in;
+  if (a.ZI <= 0) a.ZI = 1;
+  if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;
+  if (a.ks == 1 && (a.stride != 1 || a.ups)) return hipErrorInvalidValue;
+  if (a.bT && a.ks != 1) return hipErrorInvalidValue;
+  int tile = a.tile ? a.tile : auto_tile(a);
+  if (a.stride == 2) tile = TILE_64x64;
+  using T128x128_3 = TileCfg<2, 2, 2, 2, 3, 1>;
+  using T128x64_3 = TileCfg<2, 2, 2, 1, 3, 1>;
+  using T64x64_3 = TileCfg<2, 2, 1, 1, 3, 1>;
+  using T128x32_3 = TileCfg<4, 1, 1, 1, 3, 1>;
+  using T64x64_3s2 = TileCfg<2, 2, 1, 1, 3, 2>;
+  using T128x128_1 = TileCfg<2, 2, 2, 2, 1, 1>;
+  using T128x64_1 = TileCfg<2, 2, 2, 1, 1, 1>;
+  using T64x64_1 = TileCfg<2, 2, 1, 1, 1, 1>;
+  using T128x32_1 = TileCfg<4, 1, 1, 1, 1, 1>;
+  if (a.ks == 3) {
+    if (a.stride == 2) return launch_tile<T64x64_3s2>(a, s);
+    switch (tile) {
+      case TILE_128x128: return launch_tile<T128x128_3>(a, s);
+      case TILE_128x64: return launch_tile<T128x64_3>(a, s);
+      case TILE_64x64: return launch_tile<T64x64_3>(a, s);
+      case TILE_128x32: return launch_tile<T128x32_3>(a, s);
+    }
+  } else {
+    switch (tile) {
+      case TILE_128x128: return launch_tile<T128x128_1>(a, s);
+      case TILE_128x64: return launch_tile<T128x64_1>(a, s);
+      case TILE_64x64: return launch_tile<T64x64_1>(a, s);
+      case TILE_128x32: return launch_tile<T128x32_1>(a, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+void gemm_work(const GemmArgs& a, double* flops, double* bytes) {
+  const double M = (double)a.Hout * a.Wout * a.Z;
+  const double K = (double)a.ks * a.ks * a.Cin;
+  *flops = 2.0 * M * a.Cout * K;
+  const double in_elems = (double)a.Hin * a.Win * a.Cin * a.Z;
+  const double w_elems = (a.w_zo || a.w_zi) ? K * a.Cout * a.Z : K * a.Cout;
+  double out_elems = M * a.Cout;
+  if (a.resid) out_elems += M * a.Cout;
+  *bytes = 4.0 * (in_elems + w_elems + out_elems);
+}
+
+// =====================================================================================================
+// GroupNorm(32) statistics -> per-(image, channel) scale/shift   (models/ddpm/diffusion.py:68-69)
+// deterministic: per-block per-channel double partials, fixed-order finalize (batch invariant)
+// =====================================================================================================
+static inline int gn_ppb(int HW) {   // pixels per block
+  int ppb = HW / 64;
+  if (ppb < 64) ppb = 64;
+  if (ppb > HW) ppb = HW;
+  return ppb;
+}
+static inline int gn_nblk(int HW) { const int ppb = gn_ppb(HW); return (HW + ppb - 1) / ppb; }
+
+size_t gn_partial_doubles(int N, int C, int HW) { return (size_t)N * gn_nblk(HW) * C * 2; }
+
+__global__ void gn_partial_kernel(const GnArgs p, int ppb, int nblk, int Q, int PL) {
+  extern __shared__ __attribute__((aligned(16))) double gsm[];   // [PL][C][2]
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int tid = threadIdx.x, q = tid % Q, pl = tid / Q;
+  const int c = q * 4;
+  const float* src;
+  int ld;
+  if (c < p.c0) { src = p.a0 + (long long)n * p.a0_z + c; ld = p.lda0; }
+  else { src = p.a1 + (long long)n * p.a1_z + (c - p.c0); ld = p.lda1; }
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  const int pend = min(p.HW, (blk + 1) * ppb);
+  for (int pix = blk * ppb + pl; pix < pend; pix += PL) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (long long)pix * ld);
+    s[0] += v.x; ss[0] += (double)v.x * v.x;
+    s[1] += v.y; ss[1] += (double)v.y * v.y;
+    s[2] += v.z; ss[2] += (double)v.z * v.z;
+    s[3] += v.w; ss[3] += (double)v.w * v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gsm[((size_t)pl * p.C + c + j) * 2 + 0] = s[j];
+    gsm[((size_t)pl * p.C + c + j) * 2 + 1] = ss[j];
+  }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = 0, b = 0;
+      for (int l = 0; l < PL; ++l) {
+        a += gsm[((size_t)l * p.C + c + j) * 2 + 0];
+        b += gsm[((size_t)l * p.C + c + j) * 2 + 1];
+      }
+      double* dst = p.partial + (((size_t)n * nblk + blk) * p.C + c + j) * 2;
+      dst[0] = a;
+      dst[1] = b;
+    }
+  }
+}
+
+__global__ void gn_finalize_kernel(const GnArgs p, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) double gsm[];   // [C][2] + [32][2]
+  double* chs = gsm;
+  double* grp = gsm + (size_t)p.C * 2;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < p.C; c += blockDim.x) {
+    double a = 0, b = 0;
+    for (int k = 0; k < nblk; ++k) {
+      const double* src = p.partial + (((size_t)n * nblk + k) * p.C + c) * 2;
+      a += src[0];
+      b += src[1];
+    }
+    chs[c * 2] = a;
+    chs[c * 2 + 1] = b;
+  }
+  __syncthreads();
+  const int cg = p.C / 32;
+  if (tid < 32) {
+    double a = 0, b = 0;
+    for (int j = 0; j < cg; ++j) { a += chs[(tid * cg + j) * 2]; b += chs[(tid * cg + j) * 2 + 1]; }
+    const double cnt = (double)cg * p.HW;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0) var = 0;
+    grp[tid * 2] = mean;
+    grp[tid * 2 + 1] = 1.0 / sqrt(var + (double)p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < p.C; c += blockDim.x) {
+    const int g = c / cg;
+    const double mean = grp[g * 2], rstd = grp[g * 2 + 1];
+    double sc = (double)p.gamma[c] * rstd;
+    double sh = (double)p.beta[c] - mean * sc;
+    if (p.film_scale) {   // h = GN(h)*(1+scale)+shift  (models/improved_ddpm/unet.py:290-294)
+      const double f = 1.0 + (double)p.film_scale[(size_t)n * p.ld_film + c];
+      sc *= f;
+      sh = sh * f + (double)p.film_shift[(size_t)n * p.ld_film + c];
+    }
+    p.scale[(size_t)n * p.C + c] = (float)sc;
+    p.shift[(size_t)n * p.C + c] = (float)sh;
+  }
+}
+
+hipError_t launch_gn(const GnArgs& a, hipStream_t s) {
+  if (a.C % 32 != 0 || (a.c0 & 3) || (a.c1 & 3) || (a.lda0 & 3) || (a.a1 && (a.lda1 & 3))) return hipErrorInvalidValue;
+  const int Q = a.C / 4;
+  const int PL = Q >= 256 ? 1 : 256 / Q;
+  const int ppb = gn_ppb(a.HW), nblk = gn_nblk(a.HW);
+  if (Q * PL > 1024) return hipErrorInvalidValue;
+  const size_t sm1 = (size_t)PL * a.C * 2 * sizeof(double);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, a.N), dim3(Q * PL), sm1, s, a, ppb, nblk, Q, PL);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const size_t sm2 = ((size_t)a.C * 2 + 64) * sizeof(double);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.N), dim3(256), sm2, s, a, nblk);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// row softmax (models/ddpm/diffusion.py:214), one wave per row
+// =====================================================================================================
+__global__ void softmax_rows_kernel(float* x, long long rows, int T) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* r = x + row * T;
+  float mx = -INFINITY;
+  for (int i = lane; i < T; i += 64) mx = fmaxf(mx, r[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int i = lane; i < T; i += 64) {
+    const float e = expf(r[i] - mx);
+    r[i] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  for (int i = lane; i < T; i += 64) r[i] = r[i] / sum;
+}
+
+hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s) {
+  const int wpb = 4;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, x, rows, T);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// timestep embedding MLP (models/ddpm/diffusion.py:42-60, :477-480; improved_ddpm/nn.py:103-121)
+// =====================================================================================================
+__global__ void temb_mlp_kernel(const float* t, const float* freqs, int half, int sin_first, const float* w0,
+                                const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
+                                float* temb_act) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];   // emb[ch] + h0[temb_ch]
+  float* emb = tsm;
+  float* h0 = tsm + ch;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float tv = t[b];
+  for (int i = tid; i < ch; i += blockDim.x) {
+    float v = 0.f;
+    if (i < 2 * half) {
+      const int k = (i < half) ? i : i - half;
+      const float arg = tv * freqs[k];                       // fp32 product, as the reference
+      const bool is_sin = sin_first ? (i < half) : (i >= half);
+      v = is_sin ? (float)sin((double)arg) : (float)cos((double)arg);
+    }
+    emb[i] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < temb_ch; j += blockDim.x) {
+    const float* wr = w0 + (size_t)j * ch;
+    float acc = 0.f;
+    for (int i = 0; i < ch; ++i) acc = fmaf(wr[i], emb[i], acc);
+    h0[j] = silu_f(acc + b0[j]);
+  }
+  __syncthreads();
+  for (int j = tid; j < temb_ch; j += blockDim.x) {
+    const float* wr = w1 + (size_t)j * temb_ch;
+    float acc = 0.f;
+    for (int i = 0; i < temb_ch; ++i) acc = fmaf(wr[i], h0[i], acc);
+    const float v = acc + b1[j];
+    temb[(size_t)b * temb_ch + j] = v;
+    temb_act[(size_t)b * temb_ch + j] = silu_f(v);
+  }
+}
+
+hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin_first, const float* w0,
+                           const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
+                           float* temb_act, int B, hipStream_t s) {
+  const size_t sm = (size_t)(ch + temb_ch) * sizeof(float);
+  hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), sm, s, t, freqs, half, sin_first, w0, b0, w1, b1, ch,
+                     temb_ch, temb, temb_act);
+  return hipGetLastError();
+}
+
+// out[b][o] = sum_i W[o][i] * x[b][i] + bias[o]; one wave per output row, all images
+__global__ void linear_rows_kernel(const float* x, int ldx, const float* W, const float* bias, int I, int O,
+                                   float* out, int ldo, int B) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (o >= O) return;
+  const float* wr = W + (size_t)o * I;
+  const float bo = bias ? bias[o] : 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xr = x + (size_t)b * ldx;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) acc = fmaf(wr[i], xr[i], acc);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+    if (lane == 0) out[(size_t)b * ldo + o] = acc + bo;
+  }
+}
+
+hipError_t launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, int I, int O, float* out,
+                              int ldo, int B, hipStream_t s) {
+  const int wpb = 4;
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((O + wpb - 1) / wpb), dim3(wpb * 64), 0, s, x, ldx, W, bias, I, O, out,
+                     ldo, B);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// h-space mix: h2 = h*c0; h2 += d_i*c_{i+1}   (models/ddpm/diffusion.py:513-516), no fma contraction
+// =====================================================================================================
+struct MixArgs { const float* h; const float* d[4]; float c[5]; int n_d; float* out; long long n; };
+
+__global__ void mix_kernel(const MixArgs a) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    float v = __fmul_rn(a.h[i], a.c[0]);
+    for (int k = 0; k < a.n_d; ++k) v = __fadd_rn(v, __fmul_rn(a.d[k][i], a.c[k + 1]));
+    a.out[i] = v;
+  }
+}
+
+hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2, long long n,
+                      hipStream_t s) {
+  if (n_d < 0 || n_d > 4) return hipErrorInvalidValue;
+  MixArgs a;
+  a.h = h; a.n_d = n_d; a.out = h2; a.n = n;
+  for (int k = 0; k < 4; ++k) a.d[k] = (k < n_d) ? d[k] : nullptr;
+  for (int k = 0; k < 5; ++k) a.c[k] = (k <= n_d) ? coeff_host[k] : 0.f;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(mix_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// layout conversion at the reference boundary (NCHW fp32 <-> internal NHWC)
+// =====================================================================================================
+__global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int C, int HW, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long np = i / C;
+    const long long n = np / HW, pix = np - n * HW;
+    dst[i] = src[(n * C + c) * HW + pix];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* src, int lds, float* dst, int C, int HW, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % HW;
+    const long long nc = i / HW;
+    const long long n = nc / C;
+    const int c = (int)(nc - n * C);
+    dst[i] = src[(n * HW + pix) * lds + c];
+  }
+}
+static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, hipStream_t s) {
+  const long long total = (long long)N * C * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, C, HW, total);
+  return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float* src, int lds, float* dst, int N, int C, int HW, hipStream_t s) {
+  const long long total = (long long)N * C * HW;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, lds, dst, C, HW, total);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// DDIM update (utils/diffusion_utils.py:84-100), same fp32 operation order, no contraction
+// =====================================================================================================
+__global__ void ddim_kernel(const DdimArgs a) {
+  const float one_m_at = __fsub_rn(1.0f, a.at);
+  const float s1 = __fsqrt_rn(one_m_at), s2 = __fsqrt_rn(a.at);
+  const float one_m_an = __fsub_rn(1.0f, a.at_next);
+  const float sa = __fsqrt_rn(a.at_next), sb = __fsqrt_rn(one_m_an);
+  float c1 = 0.f, c2 = 0.f;
+  if (a.eta != 0.f) {
+    const float r = __fdiv_rn(a.at, a.at_next);
+    const float u = __fdiv_rn(__fmul_rn(__fsub_rn(1.0f, r), one_m_an), one_m_at);
+    c1 = __fmul_rn(a.eta, __fsqrt_rn(u));
+    c2 = __fsqrt_rn(__fsub_rn(one_m_an, __fmul_rn(c1, c1)));
+  }
+  const long long total = a.npix * 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / 3;
+    const int c = (int)(i - pix * 3);
+    const float x = a.xt[i];
+    const float e = a.et[pix * a.ld_e + c];
+    const float em = a.et_mod ? a.et_mod[pix * a.ld_e + c] : e;
+    const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(em, s1)), s2);
+    float xn;
+    if (a.eta == 0.f) {
+      xn = __fadd_rn(__fmul_rn(sa, x0), __fmul_rn(sb, e));
+    } else {
+      xn = __fadd_rn(__fadd_rn(__fmul_rn(sa, x0), __fmul_rn(c2, e)), __fmul_rn(c1, a.noise[i]));
+    }
+    if (a.apply_dt) xn = __fadd_rn(__fmul_rn(sa, x0), __fmul_rn(__fmul_rn(sb, e), a.dt_lambda));
+    a.xt_next[i] = xn;
+    if (a.x0_t) a.x0_t[i] = x0;
+  }
+}
+
+hipError_t launch_ddim(const DdimArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_kernel, dim3(ew_blocks(a.npix * 3)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace asyrp

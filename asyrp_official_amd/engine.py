@@ -1,0 +1,179 @@
+"""Thin object wrapper over the C ABI: one Engine = one asyrp_engine on one GPU."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channels, ch, ch_mult, num_res_blocks,
+                attn_resolutions, num_head_channels=0, n_delta=0):
+    cfg = _lib.AsyrpConfig()
+    cfg.family, cfg.resolution, cfg.in_channels, cfg.out_channels = family, resolution, in_channels, out_channels
+    cfg.ch, cfg.n_levels, cfg.num_res_blocks = ch, len(ch_mult), num_res_blocks
+    for i, m in enumerate(ch_mult):
+        cfg.ch_mult[i] = int(m)
+    cfg.n_attn = len(attn_resolutions)
+    for i, r in enumerate(attn_resolutions):
+        cfg.attn_resolutions[i] = int(r)
+    cfg.num_head_channels, cfg.n_delta = num_head_channels, n_delta
+    return cfg
+
+
+def param_specs(cfg):
+    """[(state_dict key, shape)] the engine expects for `cfg` — works without a GPU."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.asyrp_create(C.byref(h), C.byref(cfg), 1, 0))
+    try:
+        out = []
+        key, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        for i in range(lib.asyrp_num_params(h)):
+            _lib.check(lib.asyrp_param_info(h, i, C.byref(key), shape, C.byref(nd)))
+            out.append((key.value.decode(), tuple(int(shape[d]) for d in range(nd.value))))
+        return out
+    finally:
+        lib.asyrp_destroy(h)
+
+
+def ddpm_temb_freqs(ch):
+    """exp(arange(half) * -(ln 1e4/(half-1))) in fp32, the very ops of models/ddpm/diffusion.py:51-54."""
+    half = ch // 2
+    rate = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -rate)
+
+
+def alphas_cumprod_from_betas(betas):
+    """(1 - b).cumprod(0) in fp32 on the CPU, as utils/diffusion_utils.py:67 evaluates it."""
+    return (1.0 - betas.detach().float().cpu()).cumprod(dim=0)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise AsyrpDeviceError(f"{name} must be a float32 CUDA(HIP) tensor — the Asyrp engine has no CPU path")
+    return t.contiguous()
+
+
+class AsyrpDeviceError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, cfg, max_batch, device_index):
+        self.lib = _lib.load()
+        self.cfg, self.max_batch, self.device_index = cfg, int(max_batch), int(device_index)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.asyrp_create(C.byref(self.h), C.byref(cfg), self.max_batch, self.device_index))
+        self.out_channels, self.resolution = cfg.out_channels, cfg.resolution
+        self.bott_ch = cfg.ch * cfg.ch_mult[cfg.n_levels - 1]
+        self.bott_res = cfg.resolution >> (cfg.n_levels - 1)
+
+    def close(self):
+        if self.h:
+            self.lib.asyrp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------------
+    def load_param(self, key, tensor):
+        a = np.ascontiguousarray(tensor.detach().float().cpu().numpy())
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        _lib.check(self.lib.asyrp_load_param(self.h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def set_schedule(self, alphas_cumprod):
+        a = np.ascontiguousarray(alphas_cumprod.detach().float().cpu().numpy())
+        _lib.check(self.lib.asyrp_set_schedule(self.h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def set_temb_freqs(self, freqs):
+        a = np.ascontiguousarray(freqs.detach().float().cpu().numpy())
+        _lib.check(self.lib.asyrp_set_temb_freqs(self.h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def finalize(self):
+        _lib.check(self.lib.asyrp_finalize_params(self.h))
+
+    def device_bytes(self):
+        return int(self.lib.asyrp_device_bytes(self.h))
+
+    # ---- compute ----------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+
+    def _coeff(self, hs_coeff, index):
+        if index is None or index < 0:
+            return None, 0
+        hs = [float(v) for v in (hs_coeff if isinstance(hs_coeff, (tuple, list)) else (hs_coeff,))]
+        arr = (C.c_float * len(hs))(*hs)
+        return arr, len(hs)
+
+    def unet_forward(self, x, t, index=None, apply_edit=False, hs_coeff=(1.0, 1.0), ignore_timestep=False):
+        x = _dev_f32(x, "x")
+        t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
+        B = x.shape[0]
+        idx = -1 if index is None else int(index)
+        R, br, bc = self.resolution, self.bott_res, self.bott_ch
+        et = torch.empty((B, self.out_channels, R, R), device=x.device, dtype=torch.float32)
+        et_mod = torch.empty_like(et) if idx >= 0 else None
+        dh = torch.empty((B, bc, br, br), device=x.device, dtype=torch.float32) if (idx >= 0 and apply_edit) else None
+        mid = torch.empty((B, bc, br, br), device=x.device, dtype=torch.float32)
+        coeff, ncoeff = self._coeff(hs_coeff, idx)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_unet_forward(self.h, _ptr(x), _ptr(t), B, idx, int(bool(apply_edit)), coeff,
+                                                   ncoeff, int(bool(ignore_timestep)), _ptr(et), _ptr(et_mod),
+                                                   _ptr(dh), _ptr(mid), self._stream()))
+        return et, et_mod, dh, mid
+
+    def ddim_step(self, xt, t, t_next, *, eta=0.0, noise=None, learn_sigma=False, index=None, apply_edit=False,
+                  hs_coeff=(1.0, 1.0), ignore_timestep=False, dt_lambda=1.0, dt_end=999):
+        xt = _dev_f32(xt, "xt")
+        noise = _dev_f32(noise, "noise") if noise is not None else None
+        B = xt.shape[0]
+        idx = -1 if index is None else int(index)
+        br, bc = self.bott_res, self.bott_ch
+        xn, x0t = torch.empty_like(xt), torch.empty_like(xt)
+        dh = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32) if (idx >= 0 and apply_edit) else None
+        mid = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
+        coeff, ncoeff = self._coeff(hs_coeff, idx)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_ddim_step(self.h, _ptr(xt), int(t), int(t_next), B, float(eta), _ptr(noise),
+                                                int(bool(learn_sigma)), idx, int(bool(apply_edit)), coeff, ncoeff,
+                                                int(bool(ignore_timestep)), float(dt_lambda), int(dt_end), _ptr(xn),
+                                                _ptr(x0t), _ptr(dh), _ptr(mid), self._stream()))
+        return xn, x0t, dh, mid
+
+    def run_edit(self, x0, seq_inv, seq_gen, *, t_edit, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
+                 learn_sigma=False, noise=None, want_latent=False):
+        x0 = _dev_f32(x0, "x0")
+        B = x0.shape[0]
+        idx = -1 if index is None else int(index)
+        si = (C.c_int32 * max(len(seq_inv), 1))(*[int(v) for v in seq_inv])
+        sg = (C.c_int32 * len(seq_gen))(*[int(v) for v in seq_gen])
+        noise = _dev_f32(noise, "noise") if noise is not None else None
+        n_noise = 0 if noise is None else int(noise.shape[0])
+        x_T = torch.empty_like(x0) if want_latent else None
+        x_edit = torch.empty_like(x0)
+        coeff, ncoeff = self._coeff(hs_coeff, idx)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_run_edit(self.h, _ptr(x0), B, si, len(seq_inv), sg, len(seq_gen), int(t_edit),
+                                               int(t_addnoise), idx, coeff, ncoeff, int(bool(learn_sigma)),
+                                               _ptr(noise), n_noise, _ptr(x_T), _ptr(x_edit), self._stream()))
+        return (x_edit, x_T) if want_latent else x_edit
+
+    # ---- profiling --------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.asyrp_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return dict(conv_ms=ms.value, conv_launches=n.value, conv_flops=fl.value, conv_bytes=by.value)

@@ -1,0 +1,171 @@
+/*
+ * asyrp.h — C ABI of the MI355X-native Asyrp DDIM sampling engine (libasyrp_hip.so).
+ *
+ * The reference (kwonminki/Asyrp_official) has no FFI layer: its seam is two Python calls,
+ *   B1  model(xt, t, index=..., t_edit=..., hs_coeff=..., delta_h=..., ...)  -> (et, et_modified, delta_h, middle_h)
+ *       utils/diffusion_utils.py:46  ->  models/ddpm/diffusion.py:473 (DDPM.forward)
+ *                                        models/improved_ddpm/unet.py:676 (UNetModel.forward)
+ *   B2  denoising_step(xt, t, t_next, *, models, logvars, b, ...)            -> (xt_next, x0_t, delta_h, middle_h)
+ *       utils/diffusion_utils.py:24-104, called from diffusion_latent.py:507 (Asyrp generation)
+ *       and :1038 (DDIM inversion).
+ * This header is what a binding for those two seams (and for the two loops around them,
+ * diffusion_latent.py:1034-1045 and :503-520) binds to.  The Python host side that mirrors the
+ * reference classes on top of it lives in asyrp_official_amd/ (ctypes).
+ *
+ * Conventions
+ *   - plain C, no torch types.  Every `const float*` / `float*` named x, t, et, ... is a DEVICE
+ *     pointer to fp32 data in the reference's own layout (NCHW, contiguous); pointers documented
+ *     as "host" are host memory.
+ *   - all work is enqueued on the caller's stream (`stream` is a hipStream_t passed as void*);
+ *     no entry point synchronises the device unless documented.
+ *   - return 0 on success, a negative ASYRP_E* code otherwise; asyrp_last_error() gives the text.
+ *     Nothing throws across the ABI.
+ *   - an engine is bound to one device and is NOT thread-safe; caller serialises.
+ *   - the caller owns every I/O buffer; the engine owns packed weights + workspace until destroy.
+ */
+#ifndef ASYRP_H
+#define ASYRP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASYRP_OK 0
+#define ASYRP_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define ASYRP_EHIP (-2)     /* HIP runtime error */
+#define ASYRP_ESTATE (-3)   /* call order violated (e.g. forward before finalize) */
+#define ASYRP_EKEY (-4)     /* unknown / missing / mis-shaped parameter key */
+
+#define ASYRP_MAX_LEVELS 8
+
+/* UNet families of the reference (diffusion_latent.py:76-126 picks one by dataset). */
+enum asyrp_family {
+  ASYRP_FAMILY_DDPM = 0, /* models/ddpm/diffusion.py:327 DDPM(config)      — CelebA-HQ, LSUN */
+  ASYRP_FAMILY_IDDPM = 1 /* models/improved_ddpm/unet.py:437 UNetModel     — AFHQ, ImageNet, MetFaces */
+};
+
+/* Hyper-parameters.  DDPM reads them from configs/<dataset>.yml `model:` (models/ddpm/diffusion.py:331-337);
+ * iDDPM/ADM from the arch dicts (models/improved_ddpm/script_util.py:5-42). */
+typedef struct asyrp_config {
+  int32_t family;                 /* enum asyrp_family */
+  int32_t resolution;             /* data.image_size / image_size */
+  int32_t in_channels;            /* 3 */
+  int32_t out_channels;           /* out_ch; 6 when learn_sigma */
+  int32_t ch;                     /* model.ch / num_channels */
+  int32_t n_levels;               /* len(ch_mult) */
+  int32_t ch_mult[ASYRP_MAX_LEVELS];
+  int32_t num_res_blocks;
+  int32_t n_attn;                 /* number of entries in attn_resolutions */
+  int32_t attn_resolutions[ASYRP_MAX_LEVELS]; /* spatial sizes at which attention runs (e.g. 16) */
+  int32_t num_head_channels;      /* iDDPM: 64; DDPM: 0 = single head over all channels */
+  int32_t n_delta;                /* number of DeltaBlocks layer_0..layer_{n-1} (setattr_layers) */
+  int32_t reserved[8];
+} asyrp_config;
+
+typedef struct asyrp_engine asyrp_engine;
+
+/* Version of this ABI (bumped on any signature change). */
+int asyrp_abi_version(void);
+
+/* Last error text of the calling thread ("" if none). */
+const char* asyrp_last_error(void);
+
+/* Create an engine on `device` able to run batches up to `max_batch` images.
+ * Replaces: model construction, diffusion_latent.py:76-126 + model.setattr_layers(get_h_num) :586. */
+int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int device);
+void asyrp_destroy(asyrp_engine* e);
+
+/* Hand one tensor of the reference state_dict to the engine (host pointer, fp32, contiguous,
+ * PyTorch layout: conv [Cout,Cin,kh,kw], linear [out,in]).  `key` is the reference's own
+ * state_dict name, e.g. "down.0.block.1.conv1.weight" or "layer_0.temb_proj.bias"
+ * (so pretrained checkpoints and checkpoint/<name>.pth["0"] load unmodified).
+ * Replaces: load_state_dict, diffusion_latent.py:124 and :663-676. */
+int asyrp_load_param(asyrp_engine* e, const char* key, const float* host_data, const int64_t* shape, int ndim);
+
+/* Diffusion schedule table, host pointer: alphas_cumprod[n] = cumprod(1-beta) computed by the caller
+ * exactly as utils/diffusion_utils.py:67 does (fp32 cumprod of the fp32 betas). */
+int asyrp_set_schedule(asyrp_engine* e, const float* alphas_cumprod_host, int n);
+
+/* Sinusoidal-embedding frequencies, host pointer [ch/2], computed by the caller exactly as
+ * models/ddpm/diffusion.py:52-54 (or improved_ddpm/nn.py:113-116) does, so they are bit-identical. */
+int asyrp_set_temb_freqs(asyrp_engine* e, const float* freqs_host, int n);
+
+/* Pack every loaded parameter into the kernel layout and upload.  Must be called after the last
+ * asyrp_load_param and before any compute call; may be called again after re-loading some keys
+ * (e.g. another Δh checkpoint).  Fails with ASYRP_EKEY if a required key is missing. */
+int asyrp_finalize_params(asyrp_engine* e);
+
+/* Number of parameter keys the engine expects, and the i-th key / its shape (for loaders). */
+int asyrp_num_params(const asyrp_engine* e);
+int asyrp_param_info(const asyrp_engine* e, int i, const char** key, int64_t shape[4], int* ndim);
+
+/* B1 — one UNet evaluation (DDPM.forward, models/ddpm/diffusion.py:473-580).
+ *   x [B,Cin,R,R], t [B] (float timesteps, device).
+ *   index < 0  == index=None: single decoder; et_mod / delta_h_out are not written.
+ *   index >= 0: DeltaBlocks layer_0..layer_index are summed (:513-516) when `apply_edit` != 0
+ *               (the caller evaluates the reference's `t[0] >= t_edit` test, :510); with
+ *               apply_edit == 0 the decoder input is h itself and et_mod == et bit-for-bit (:541-542).
+ *   hs_coeff: host pointer, n_coeff = index+2 floats (c0, c1, ...).
+ *   ignore_timestep: DeltaBlock gets temb=None (:514).
+ *   outputs: et [B,Cout,R,R]; et_mod [B,Cout,R,R] (nullable); delta_h_out [B,Cb,Rb,Rb] (nullable; the
+ *   LAST DeltaBlock's raw output as the reference returns it); middle_h [B,Cb,Rb,Rb] (nullable). */
+int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, int index, int apply_edit,
+                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* et, float* et_mod,
+                       float* delta_h_out, float* middle_h, void* stream);
+
+/* B2 — one fused DDIM step = UNet + update (denoising_step, utils/diffusion_utils.py:24-104,
+ * sampling_type='ddim').  t / t_next are host ints shared by the batch (the reference builds
+ * them as ones(B)*i, diffusion_latent.py:504-505); t_next = -1 means alpha_bar_next = 1 (:68-69).
+ *   eta != 0 requires `noise` [B,3,R,R] (stands in for torch.randn_like, :97).
+ *   learn_sigma: eps = first half of the output channels (:47-51).
+ *   dt_lambda/dt_end: :99-100.  index/apply_edit/hs_coeff/ignore_timestep as above.
+ *   outputs: xt_next, x0_t [B,3,R,R]; delta_h_out, middle_h nullable. */
+int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, float eta, const float* noise,
+                    int learn_sigma, int index, int apply_edit, const float* hs_coeff_host, int n_coeff,
+                    int ignore_timestep, float dt_lambda, int dt_end, float* xt_next, float* x0_t,
+                    float* delta_h_out, float* middle_h, void* stream);
+
+/* The two hot loops back to back (diffusion_latent.py:1034-1045 then :503-520):
+ *   x0 [B,3,R,R] --(n_inv-1 inversion steps over seq_inv)--> x_T --(n_gen Asyrp steps over seq_gen)--> x_edit.
+ *   seq_inv / seq_gen: host int arrays, ascending timesteps exactly as diffusion_latent.py:955-957 builds them.
+ *   n_inv == 0 skips inversion and starts generation from x0 interpreted as x_T.
+ *   The edit is applied for steps with t >= t_edit; eta = 1 for steps with t < t_addnoise, consuming
+ *   noise[k] ([n_noise,B,3,R,R], nullable when no such step) in step order.
+ *   x_T (nullable) receives the inverted latent. */
+int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv_host, int n_inv,
+                   const int32_t* seq_gen_host, int n_gen, int t_edit, int t_addnoise, int index,
+                   const float* hs_coeff_host, int n_coeff, int learn_sigma, const float* noise, int n_noise,
+                   float* x_T, float* x_edit, void* stream);
+
+/* Bytes of device memory held by the engine (weights + workspace). */
+int64_t asyrp_device_bytes(const asyrp_engine* e);
+
+/* ---- profiling hooks (used by bench.py for the roofline object) ------------------------------ */
+/* Enable/disable per-kernel-family HIP-event timing on the launch stream.  While enabled every
+ * launch of the dominant kernel family (implicit-GEMM conv) is bracketed by hipEvents. */
+int asyrp_profile_enable(asyrp_engine* e, int on);
+/* After a device sync: total time (ms), launch count and algorithmic FLOPs / bytes of the conv
+ * launches recorded since the last reset; resets the record. */
+int asyrp_profile_read(asyrp_engine* e, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                       double* conv_bytes);
+
+/* ---- op-level test hooks (tests/ only; same kernels the engine launches) ---------------------- */
+/* y = conv2d(act(x)) [+bias] [+ per-image channel vector] [+ residual], NCHW fp32 in and out.
+ *   x0 [B,C0,H,W] (+ optional x1 [B,C1,H,W] = channel concat), weight [Cout,C0+C1,k,k] (k = 1 or 3),
+ *   stride 1 (pad k/2) or 2 (DDPM Downsample: pad right/bottom, models/ddpm/diffusion.py:103-107),
+ *   upsample: nearest x2 before the conv (:84-85).
+ *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0). */
+int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                    const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
+                    const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,
+                    const float* residual, float* y, void* stream);
+/* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
+ * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T]. */
+int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASYRP_H */

@@ -1,0 +1,150 @@
+"""Op-level parity of the HIP kernels (through the C ABI test hooks) against torch-CPU fp32 —
+the same ATen ops the reference dispatches."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+from oracle.weights import hash_normal, hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def hip_conv(x0, w, b, *, x1=None, stride=1, upsample=False, gn=None, silu=False, chan_add=None, residual=None):
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    dev = "cuda"
+    B, C0, H, W = x0.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
+    if stride == 2:
+        Ho, Wo = Ho // 2, Wo // 2
+    d = lambda t: None if t is None else t.to(dev).contiguous()
+    x0d, x1d, wd, bd, cad, rd = d(x0), d(x1), d(w), d(b), d(chan_add), d(residual)
+    gw, gb = (d(gn[0]), d(gn[1])) if gn else (None, None)
+    y = torch.empty((B, Cout, Ho, Wo), device=dev)
+    _lib.check(lib.asyrp_op_conv2d(0, _p(x0d), C0, _p(x1d), 0 if x1 is None else x1.shape[1], B, H, W, _p(wd), _p(bd),
+                                   Cout, k, stride, int(upsample), _p(gw), _p(gb), 1e-6, int(silu), _p(cad), _p(rd),
+                                   _p(y), None))
+    torch.cuda.synchronize()
+    return y.cpu()
+
+
+def ref_conv(x0, w, b, *, x1=None, stride=1, upsample=False, gn=None, silu=False, chan_add=None, residual=None):
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+    if gn:
+        x = F.group_norm(x, 32, gn[0], gn[1], eps=1e-6)
+    if silu:
+        x = x * torch.sigmoid(x)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    k = w.shape[-1]
+    if stride == 2:
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        y = F.conv2d(x, w, b, padding=k // 2)
+    if chan_add is not None:
+        y = y + chan_add[:, :, None, None]
+    if residual is not None:
+        y = residual + y
+    return y
+
+
+def _mk(B, Cin, Cout, H, k, tag):
+    x = hash_normal(f"{tag}.x", (B, Cin, H, H))
+    w = hash_uniform(f"{tag}.w", (Cout, Cin, k, k), -1, 1) / (Cin * k * k) ** 0.5
+    b = 0.1 * hash_uniform(f"{tag}.b", (Cout,))
+    return x, w, b
+
+
+TIGHT = dict(rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 32, 32, 16), (1, 128, 128, 32), (2, 64, 96, 8), (3, 32, 64, 24),
+                                          (1, 256, 512, 8), (2, 3, 32, 16), (2, 32, 3, 16), (1, 96, 160, 20)])
+def test_conv3x3_plain(B, Cin, Cout, H):
+    x, w, b = _mk(B, Cin, Cout, H, 3, f"c3.{B}.{Cin}.{Cout}.{H}")
+    assert_close(hip_conv(x, w, b), ref_conv(x, w, b), what="conv3x3", **TIGHT)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 32, 64, 16), (1, 256, 128, 32), (2, 64, 64, 8), (1, 512, 1536, 8)])
+def test_conv1x1(B, Cin, Cout, H):
+    x, w, b = _mk(B, Cin, Cout, H, 1, f"c1.{B}.{Cin}.{Cout}.{H}")
+    assert_close(hip_conv(x, w, b), ref_conv(x, w, b), what="conv1x1", **TIGHT)
+
+
+def test_conv3x3_gn_silu_prologue_and_epilogue():
+    B, Cin, Cout, H = 2, 64, 32, 16
+    x, w, b = _mk(B, Cin, Cout, H, 3, "fused")
+    gn = (1 + 0.1 * hash_uniform("fused.g", (Cin,)), 0.1 * hash_uniform("fused.be", (Cin,)))
+    ca = hash_normal("fused.ca", (B, Cout))
+    res = hash_normal("fused.res", (B, Cout, H, H))
+    kw = dict(gn=gn, silu=True, chan_add=ca, residual=res)
+    assert_close(hip_conv(x, w, b, **kw), ref_conv(x, w, b, **kw), what="fused resblock conv", **TIGHT)
+
+
+def test_conv3x3_concat_two_sources_group_straddle():
+    # 64 + 32 = 96 channels -> 3 per group: groups straddle the two sources (like 512+256 in up.4)
+    B, H = 2, 16
+    x0 = hash_normal("cat.x0", (B, 64, H, H)) + 0.5
+    x1 = 2.0 * hash_normal("cat.x1", (B, 32, H, H)) - 0.3
+    _, w, b = _mk(B, 96, 64, H, 3, "cat")
+    gn = (1 + 0.1 * hash_uniform("cat.g", (96,)), 0.1 * hash_uniform("cat.be", (96,)))
+    kw = dict(x1=x1, gn=gn, silu=True)
+    assert_close(hip_conv(x0, w, b, **kw), ref_conv(x0, w, b, **kw), what="concat conv", **TIGHT)
+
+
+def test_conv3x3_stride2_asymmetric_pad():
+    for (B, C, H) in [(2, 32, 16), (1, 128, 32), (1, 64, 8)]:
+        x, w, b = _mk(B, C, C, H, 3, f"s2.{C}.{H}")
+        assert_close(hip_conv(x, w, b, stride=2), ref_conv(x, w, b, stride=2), what="downsample conv", **TIGHT)
+
+
+def test_conv3x3_nearest_upsample():
+    for (B, C, H) in [(2, 32, 8), (1, 64, 16), (1, 128, 4)]:
+        x, w, b = _mk(B, C, C, H, 3, f"up.{C}.{H}")
+        assert_close(hip_conv(x, w, b, upsample=True), ref_conv(x, w, b, upsample=True), what="upsample conv", **TIGHT)
+
+
+def test_gn_without_silu_is_the_attention_norm():
+    B, C, H = 2, 64, 8
+    x, w, b = _mk(B, C, 3 * C, H, 1, "qkv")
+    gn = (1 + 0.1 * hash_uniform("qkv.g", (C,)), 0.1 * hash_uniform("qkv.be", (C,)))
+    assert_close(hip_conv(x, w, b, gn=gn), ref_conv(x, w, b, gn=gn), what="qkv conv", **TIGHT)
+
+
+def test_gn_large_mean_offset_is_stable():
+    B, C, H = 1, 32, 32
+    x, w, b = _mk(B, C, C, H, 3, "off")
+    x = x + 30.0     # |mean| >> std: E[x^2]-mean^2 must not lose the variance
+    gn = (torch.ones(C), torch.zeros(C))
+    assert_close(hip_conv(x, w, b, gn=gn, silu=True), ref_conv(x, w, b, gn=gn, silu=True), what="gn offset",
+                 rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,T,heads", [(2, 64, 64, 1), (1, 512, 256, 1), (2, 128, 64, 2), (1, 512, 256, 8)])
+def test_attention(B, C, T, heads):
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    qkv = hash_normal(f"att.{B}.{C}.{T}.{heads}", (B, 3 * C, T))
+    out = torch.empty((B, C, T), device="cuda")
+    qd = qkv.cuda()
+    _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, _p(out), None))
+    torch.cuda.synchronize()
+    if heads == 1:      # models/ddpm/diffusion.py:205-221
+        q, k, v = qkv.split(C, dim=1)
+        w = torch.bmm(q.transpose(1, 2), k) * (C ** -0.5)
+        ref = torch.bmm(v, F.softmax(w, dim=2).transpose(1, 2))
+    else:               # QKVAttentionLegacy, models/improved_ddpm/unet.py:379-396
+        ch = C // heads
+        q, k, v = qkv.reshape(B * heads, ch * 3, T).split(ch, dim=1)
+        scale = 1 / (ch ** 0.5) ** 0.5
+        w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+        ref = torch.einsum("bts,bcs->bct", F.softmax(w.float(), dim=-1), v).reshape(B, -1, T)
+    assert_close(out.cpu(), ref, what="attention", **TIGHT)

@@ -1,0 +1,90 @@
+"""B1 parity: the HIP DDPM.forward against (i) fixtures produced by the reference itself and
+(ii) the CPU oracle on the same seeded inputs.  Tolerance = north-star rtol=1e-3 / atol=1e-4."""
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle.ddpm import ddpm_forward
+from oracle.weights import CELEBA, SMALL, hash_normal
+from util_models import err_stats, hip_model, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    sd = synthetic(SMALL, 2, seed=7)
+    return hip_model(SMALL, sd, 2), sd, hash_normal("small.x", (2, 3, 32, 32), seed=1)
+
+
+def test_small_forward_single(small, golden_small):
+    m, _, x = small
+    t = torch.ones(2, device="cuda") * 701.0
+    et, em, dh, mh = m(x.cuda(), t)
+    assert em is None and dh is None
+    assert_close(et, golden_small["fwd_single.et"], what="et")
+    assert_close(mh, golden_small["fwd_single.middle_h"], what="middle_h")
+
+
+def test_small_forward_dual(small, golden_small):
+    m, _, x = small
+    g = golden_small
+    t = torch.ones(2, device="cuda") * 701.0
+    et, em, dh, mh = m(x.cuda(), t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    assert_close(et, g["fwd_dual.et"], what="et")
+    assert_close(em, g["fwd_dual.et_mod"], what="et_mod")
+    assert_close(dh, g["fwd_dual.delta_h"], what="delta_h")
+    assert_close(mh, g["fwd_dual.middle_h"], what="middle_h")
+
+
+def test_small_forward_variants(small, golden_small):
+    m, _, x = small
+    g = golden_small
+    t = torch.ones(2, device="cuda") * 701.0
+    et, em, dh, _ = m(x.cuda(), t, index=1, t_edit=500, hs_coeff=(0.9, 0.7, 0.5))
+    assert_close(em, g["fwd_multi.et_mod"], what="multi et_mod")
+    assert_close(dh, g["fwd_multi.delta_h"], what="multi delta_h")
+    _, em, dh, _ = m(x.cuda(), t, index=0, t_edit=500, hs_coeff=(1.0, 1.0), ignore_timestep=True)
+    assert_close(em, g["fwd_ignoret.et_mod"], what="ignore_timestep et_mod")
+    assert_close(dh, g["fwd_ignoret.delta_h"], what="ignore_timestep delta_h")
+    et, em, dh, _ = m(x.cuda(), torch.ones(2, device="cuda") * 204.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    assert dh is None and torch.equal(et, em)          # reference: bitwise equal, delta_h None (Appendix B.17)
+    assert_close(et, g["fwd_noedit.et"], what="noedit et")
+
+
+def test_batch_invariance_bitwise(small):
+    """Sharding a batch must not change any image: image 1 alone == image 1 inside a batch of 2."""
+    m, _, x = small
+    xc = x.cuda()
+    t2, t1 = torch.ones(2, device="cuda") * 701.0, torch.ones(1, device="cuda") * 701.0
+    et2, em2, dh2, _ = m(xc, t2, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    et1, em1, dh1, _ = m(xc[1:2].contiguous(), t1, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    assert torch.equal(et2[1:2], et1) and torch.equal(em2[1:2], em1) and torch.equal(dh2[1:2], dh1)
+
+
+def test_cpu_input_fails_loudly(small):
+    m, _, x = small
+    from asyrp_official_amd import AsyrpDeviceError
+    with pytest.raises(AsyrpDeviceError):
+        m(x, torch.ones(2) * 701.0)
+
+
+def test_celeba_full_size_forward(golden_celeba):
+    """CelebA-HQ DDPM 256x256 (114 M params), B=1: vs the reference fixture AND the oracle run here."""
+    sd = synthetic(CELEBA, 1, seed=1234)
+    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    x = hash_normal("celeba.x", (1, 3, 256, 256), seed=1234)
+    t = torch.ones(1) * 768.0
+    et, em, dh, mh = m(x.cuda(), t.cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    g = golden_celeba
+    for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh)):
+        print(name, err_stats(got, g[name]))
+        assert_close(got, g[name], what=name)
+    et1, _, _, mh1 = m(x.cuda(), t.cuda())
+    assert_close(et1, g["fwd_single.et"], what="single et")
+    assert_close(mh1, g["fwd_single.middle_h"], what="single middle_h")
+    with torch.no_grad():
+        o_et, o_em, o_dh, o_mh = ddpm_forward(sd, CELEBA, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    assert_close(et, o_et, what="oracle et")
+    assert_close(em, o_em, what="oracle et_mod")
+    assert_close(mh, o_mh, what="oracle middle_h")
