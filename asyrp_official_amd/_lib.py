@@ -41,7 +41,8 @@ _SIGS = {
     "asyrp_run_edit": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "asyrp_device_bytes": (C.c_int64, [_P]),
     "asyrp_profile_enable": (C.c_int, [_P, _I]),
-    "asyrp_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+    "asyrp_profile_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
     "asyrp_op_conv2d": (C.c_int, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P,
                                   _P, _P]),

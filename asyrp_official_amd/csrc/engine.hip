@@ -277,7 +277,7 @@ void drop(Ctx& c, Act& a) {
   a.p = nullptr;
 }
 
-int variant_of(const GemmArgs& g) { return g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0); }
+int variant_of(const GemmArgs& g) { return gemm_resolve_tile(g) * 1000 + g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0); }
 
 int run_gemm(Ctx& c, const GemmArgs& g) {
   asyrp_engine* e = c.e;
@@ -899,25 +899,34 @@ int asyrp_profile_enable(asyrp_engine* e, int on) {
   return 0;
 }
 
-int asyrp_profile_read(asyrp_engine* e, double* conv_ms, int64_t* conv_launches, double* conv_flops,
-                       double* conv_bytes) {
+int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launches, double* flops, double* bytes,
+                       double* all_ms, double* all_flops) {
   if (!e) return fail(ASYRP_EINVAL, "null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
-  // dominant family = 3x3 stride-1 implicit-GEMM conv (variant 310)
-  double ms = 0, fl = 0, by = 0;
-  int64_t n = 0;
+  struct Acc { double ms = 0, fl = 0, by = 0; int64_t n = 0; };
+  std::map<int, Acc> acc;
+  double tms = 0, tfl = 0;
   for (auto& r : e->prof) {
     float t = 0.f;
     HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
-    if (r.variant == 310) { ms += t; fl += r.flops; by += r.bytes; ++n; }
+    Acc& a = acc[r.variant];
+    a.ms += t; a.fl += r.flops; a.by += r.bytes; a.n += 1;
+    tms += t; tfl += r.flops;
     e->ev_free.emplace_back(r.a, r.b);
   }
   e->prof.clear();
-  if (conv_ms) *conv_ms = ms;
-  if (conv_launches) *conv_launches = n;
-  if (conv_flops) *conv_flops = fl;
-  if (conv_bytes) *conv_bytes = by;
+  int best = 0;
+  Acc b;
+  for (auto& kv : acc)
+    if (kv.second.ms > b.ms) { b = kv.second; best = kv.first; }
+  if (variant) *variant = best;
+  if (ms) *ms = b.ms;
+  if (launches) *launches = b.n;
+  if (flops) *flops = b.fl;
+  if (bytes) *bytes = b.by;
+  if (all_ms) *all_ms = tms;
+  if (all_flops) *all_flops = tfl;
   return 0;
 }
 

@@ -32,6 +32,7 @@ struct GemmArgs {
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+int gemm_resolve_tile(const GemmArgs& a);   // TILE_* the launcher will pick
 // algorithmic work of one launch (2*M*N*K flops; A read once + out written once + weights once)
 void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 

@@ -360,6 +360,11 @@ static int auto_tile(const GemmArgs& a) {
   return TILE_64x64;
 }
 
+int gemm_resolve_tile(const GemmArgs& a) {
+  if (a.stride == 2) return TILE_64x64;
+  return a.tile ? a.tile : auto_tile(a);
+}
+
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.ZI <= 0) a.ZI = 1;

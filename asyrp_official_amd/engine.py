@@ -174,6 +174,14 @@ class Engine:
         _lib.check(self.lib.asyrp_profile_enable(self.h, int(bool(on))))
 
     def profile_read(self):
-        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
-        return dict(conv_ms=ms.value, conv_launches=n.value, conv_flops=fl.value, conv_bytes=by.value)
+        """Stats of the dominant implicit-GEMM kernel (and of all GEMM launches) since the last read."""
+        var, n = C.c_int(), C.c_int64()
+        ms, fl, by, ams, afl = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(var), C.byref(ms), C.byref(n), C.byref(fl),
+                                               C.byref(by), C.byref(ams), C.byref(afl)))
+        v = var.value
+        tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(v // 1000, (0, 0, 0, 0))
+        ks, stride = (v // 100) % 10, (v // 10) % 10
+        name = "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
+        return dict(variant=v, kernel=name, ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value,
+                    all_ms=ams.value, all_flops=afl.value)

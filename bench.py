@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py — edited images/sec of the Asyrp hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch: DDIM inversion (n_inv-1 = 39 UNet evaluations)
+followed by Asyrp generation (n_gen = 40 evaluations, second decoder for t >= t_edit) of B images of
+256x256 through the CelebA-HQ DDPM UNet (configs[1] of BASELINE.json: batch 32 on one MI355X).
+Inputs (x0, weights) are resident in HBM before the timed region; synthetic data, seeded random-init
+weights of the reference architecture (no checkpoints offline).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields); weak scaling: every rank edits its
+own B images with no data-path collective, then the final images are all-gathered once (RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+T_EDIT, T_0, N_INV, N_GEN = 500, 999, 40, 40
+
+CELEBA = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16],
+              in_channels=3, resolution=256)   # /root/reference/configs/celeba.yml:13-25
+
+
+def celeba_namespace():
+    c = CELEBA
+    return Namespace(model=Namespace(ch=c["ch"], out_ch=c["out_ch"], ch_mult=c["ch_mult"],
+                                     num_res_blocks=c["num_res_blocks"], attn_resolutions=c["attn_resolutions"],
+                                     dropout=0.0, in_channels=c["in_channels"], resamp_with_conv=True),
+                     data=Namespace(image_size=c["resolution"]))
+
+
+def cpu_baseline(model_cpu_sd, betas):
+    """Oracle (CPU restatement of the reference, kind="port") timed on this host's cores on a bounded sample:
+    B=1, 2 inversion steps + 2 Asyrp steps (dual decoder, as the reference executes them), extrapolated
+    linearly to the 39 + 40 steps of one edit."""
+    from oracle import sampler as osamp
+    from oracle.weights import DDPMConfig
+    # physical cores visible to this process (torch's default intra-op pool); os.cpu_count() counts SMT siblings
+    cores = max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0))))
+    torch.set_num_threads(cores)
+    cfg = DDPMConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in CELEBA.items()})
+    model = osamp.make_model(model_cpu_sd, cfg)
+    g = torch.Generator().manual_seed(1234)
+    x = 2 * torch.rand((1, 3, 256, 256), generator=g) - 1
+    one = torch.ones(1)
+    osamp.denoising_step(x, one * 0.0, one * 25.0, model=model, b=betas, eta=0)          # warm-up
+    t0 = time.perf_counter()
+    for (i, j) in ((0, 25), (25, 51)):
+        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0)
+    t_inv = (time.perf_counter() - t0) / 2
+    t0 = time.perf_counter()
+    for (i, j) in ((999, 973), (973, 947)):
+        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0, index=0, t_edit=T_EDIT,
+                                          hs_coeff=(1.0, 1.0))
+    t_gen = (time.perf_counter() - t0) / 2
+    per_image = (N_INV - 1) * t_inv + N_GEN * t_gen
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"B=1: 2 inversion + 2 dual-decoder Asyrp steps timed ({t_inv:.2f} s, {t_gen:.2f} s per step), "
+                      f"extrapolated to {N_INV - 1}+{N_GEN} steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from asyrp_official_amd import DDPM, run_edit
+    from asyrp_official_amd.diffusion_utils import get_beta_schedule
+    from asyrp_official_amd.sampler import gather_shards
+
+    B = a.batch
+    torch.manual_seed(1234)                     # main.py:301 default seed
+    model = DDPM(celeba_namespace(), max_batch=B)
+    model.setattr_layers(1)                     # get_h_num = 1
+    cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = torch.Generator().manual_seed(1234 + rank)
+    x0 = (2 * torch.rand((B, 3, 256, 256), generator=g) - 1).to(dev)
+    eng = model.engine(dev)
+    model.set_schedule(betas)
+
+    def one_step():
+        x_edit = run_edit(model, x0, betas, n_inv=N_INV, n_gen=N_GEN, t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0,
+                          hs_coeff=(1.0, 1.0))
+        if world > 1:
+            x_edit = gather_shards(x_edit, B * world)   # the one collective of the path
+        return x_edit
+
+    for _ in range(a.warmup):
+        one_step()
+    if not a.no_kernel_events:
+        torch.cuda.synchronize()
+        eng.profile_read()
+        eng.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not a.no_kernel_events:
+        eng.profile_enable(False)
+        prof = eng.profile_read()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite output"
+
+    if rank == 0:
+        images = B * world * a.steps
+        res = {
+            "metric": "edited images/sec, CelebA-HQ 256^2 40-step Asyrp, 1/2/4/8 GPU",
+            "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
+            "config": {"workload": f"CelebA-HQ DDPM 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
+                                   f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
+                       "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)"},
+        }
+        if prof and prof["launches"]:
+            ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": prof["kernel"],
+                               "launches": prof["launches"], "avg_launch_ms": prof["ms"] / prof["launches"],
+                               "flops_per_launch": prof["flops"] / prof["launches"],
+                               "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
+                               "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cpu_sd, betas)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,10 +146,14 @@ int64_t asyrp_device_bytes(const asyrp_engine* e);
 /* Enable/disable per-kernel-family HIP-event timing on the launch stream.  While enabled every
  * launch of the dominant kernel family (implicit-GEMM conv) is bracketed by hipEvents. */
 int asyrp_profile_enable(asyrp_engine* e, int on);
-/* After a device sync: total time (ms), launch count and algorithmic FLOPs / bytes of the conv
- * launches recorded since the last reset; resets the record. */
-int asyrp_profile_read(asyrp_engine* e, double* conv_ms, int64_t* conv_launches, double* conv_flops,
-                       double* conv_bytes);
+/* After a device sync: statistics of the implicit-GEMM launches recorded since the last read.
+ * The DOMINANT variant (largest accumulated time) is reported in full:
+ *   *variant = tile*1000 + ksize*100 + stride*10 + transposedB   (tile: 1=128x128, 2=128x64, 3=64x64, 4=128x32),
+ *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
+ *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
+ * Resets the record. */
+int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launches, double* flops, double* bytes,
+                       double* all_ms, double* all_flops);
 
 /* ---- op-level test hooks (tests/ only; same kernels the engine launches) ---------------------- */
 /* y = conv2d(act(x)) [+bias] [+ per-image channel vector] [+ residual], NCHW fp32 in and out.

