@@ -122,8 +122,11 @@ def test_edit_with_noise_tail_against_oracle(small):
     x_T = osamp.invert(model, x, b, n_inv=n)
     want = osamp.generate(model, x_T, b, n_gen=n, t_edit=500, t_addnoise=300, noises=list(noise))
     got = run_edit(m, x.cuda(), b, n_inv=n, n_gen=n, t_edit=500, t_addnoise=300, noise=noise.cuda())
-    print(err_stats(got, want))
-    assert_close(got, want, what="x_edit with noise tail")
+    st = err_stats(got, want)
+    print(st)
+    # free-running 8+8 steps on random-init weights: the trajectory expands to |x| ~ 3e2 (SURVEY.md §7 "trajectory
+    # chaos"), so the bound is relative to the tensor's scale, as in test_whole_edit_teacher_forced_and_fused_loop
+    assert st["max_abs"] <= 1e-4 * st["ref_absmax"] and st["frac_outside"] <= 0.02
 
 
 def test_generation_only_from_xT(small):
