@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libasyrp_hip.so")
 
 MAX_LEVELS = 8
 FAMILY_DDPM, FAMILY_IDDPM = 0, 1
+MATH_F16X3, MATH_F32 = 0, 1
+CONV_MATH = {"f16x3": MATH_F16X3, "f32": MATH_F32}
 
 
 class AsyrpConfig(C.Structure):
@@ -21,7 +23,7 @@ class AsyrpConfig(C.Structure):
                 ("out_channels", C.c_int32), ("ch", C.c_int32), ("n_levels", C.c_int32),
                 ("ch_mult", C.c_int32 * MAX_LEVELS), ("num_res_blocks", C.c_int32), ("n_attn", C.c_int32),
                 ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("num_head_channels", C.c_int32),
-                ("n_delta", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("n_delta", C.c_int32), ("conv_math", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
@@ -45,7 +47,7 @@ _SIGS = {
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
     "asyrp_op_conv2d": (C.c_int, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P,
-                                  _P, _P]),
+                                  _P, _I, _I, _P]),
     "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -1,0 +1,506 @@
+// conv_f16x3.hip — the dominant kernel of the engine: implicit-GEMM convolution on the f16 matrix cores with a
+// two-term operand split ("f16x3"), fp32-equivalent results at 16/3 x the fp32-MFMA rate.
+//
+//   y = conv(act(x), w)  with  act(x) = x_hi + x_lo,  w = w_hi + w_lo   (each term an f16, exact two-term split)
+//     ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi        (the dropped x_lo*w_lo term is 2^-22 relative)
+// Every product of two f16 values is exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32, so the
+// result differs from an fp32 fma chain only by summation order: measured max |err| 1.5e-6 on the whole CelebA-HQ
+// UNet forward (tests/experiments/split_precision_numerics.py), the same class as the fp32-MFMA kernel (3e-6).
+// gfx950 has no xf32/TF32; its fp32-input MFMA runs at 157 TFLOP/s, the f16 MFMA at 2.5 PFLOP/s dense, so three
+// f16 MFMAs per K-slice have a ceiling of 833 TFLOP/s of fp32-equivalent work.
+//
+// Data flow of one workgroup (BM output pixels x BN output channels of one image):
+//   A (activations, fp32 NHWC in HBM, up to two channel-concatenated sources, optional nearest-x2 upsample):
+//       global_load_dwordx4 -> registers -> GroupNorm-apply (per-(image,channel) scale/shift) + SiLU -> f16 hi/lo
+//       split -> ds_write_b128 into the halo tile [unit u=4][pixel][8 x f16]; the tile of one 16-channel chunk is
+//       staged ONCE and re-used by all 9 taps (LDS holds the (PH+2)x(PW+2) halo).
+//   B (weights, pre-split and pre-packed at load time in exactly the LDS image order):
+//       global_load_lds_dwordx4 (LDS-DMA, no VGPRs) one (chunk,tap) slice [u=4][BN][8 x f16] per K-step, double buffered.
+//   MFMA: per K-step (16 channels of one tap) each wave issues TM*TN*3 v_mfma_f32_32x32x16_f16 from
+//       (TM+TN)*2 ds_read_b128 fragments; "unit-major" LDS layout makes both fragment reads bank-conflict free.
+//   Epilogue: acc * alpha (undoes the power-of-two operand scales) + bias + per-image channel vector (timestep
+//       projection) + residual -> fp32 NHWC, 128-B contiguous per pixel row of a 32-channel MFMA tile.
+// Reference ops replaced: models/ddpm/diffusion.py:151-170 (ResnetBlock convs + nin_shortcut), :72-110 (Up/Downsample),
+// :179-198 (AttnBlock q,k,v,proj_out 1x1), :236-248 (DeltaBlock 1x1), :356-360/:426-430 (conv_in/conv_out).
+#include "kernels.h"
+
+namespace asyrp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int XKC = 16;                 // input channels per K-step (= K of one v_mfma_f32_32x32x16_f16)
+constexpr float ACT_SCALE = 16.0f;      // activations are multiplied by 2^4 before the split (keeps x_lo out of the
+                                        // f16 subnormal range down to |x| ~ 1e-2); folded into alpha on the host
+constexpr float H_MAX = 65504.0f;
+
+template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_>
+struct XCfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, KS = KS_, STRIDE = STRIDE_;
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int PW = (KS == 1) ? BM : (BM >= 128 ? 16 : 8);
+  static constexpr int PH = BM / PW;
+  static constexpr int TH = (PH - 1) * STRIDE + KS, TW = (PW - 1) * STRIDE + KS;
+  static constexpr int NPIX = TH * TW;
+  static constexpr int A_BYTES = NPIX * 64;            // [4 units][NPIX][16 B]
+  static constexpr int B_BYTES = BN * 64;              // [4 units][BN][16 B]
+  static constexpr int NU = NPIX * 2;                  // staging work items: (pixel, 8-channel half)
+  static constexpr int NA = (NU + NT - 1) / NT;
+  static constexpr int NTAPS = KS * KS;
+  static constexpr int NPIECE = 4 * BN / 64;           // 1-KiB LDS-DMA pieces per B slice
+  static constexpr size_t SMEM = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES;
+  static constexpr int MINW = (SMEM <= 76 * 1024) ? 2 : 1;   // workgroups per CU the LDS admits (=> waves per SIMD)
+};
+
+__device__ __forceinline__ float silu_fast(float v) {
+  // x * sigmoid(x) (models/ddpm/diffusion.py:63-65) with v_exp_f32 / v_rcp_f32 (<= 2 ulp each)
+  const float e = __expf(-v);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s = __builtin_fminf(__builtin_fmaxf(v[j] * ACT_SCALE, -H_MAX), H_MAX);
+    const _Float16 h = (_Float16)s;
+    const float r = __builtin_fminf(__builtin_fmaxf(s - (float)h, -H_MAX), H_MAX);
+    hi[j] = h;
+    lo[j] = (_Float16)r;
+  }
+}
+
+// VEC: Cin, c0, c1 and both row strides are multiples of 16 floats and the bases 16-B aligned (every layer but
+// conv_in): a K-chunk is 16 contiguous floats of ONE source per pixel -> two global_load_dwordx4 per work item.
+template <class T, bool VEC>
+__global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
+  constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, PW = T::PW, TW = T::TW;
+  constexpr int NPIX = T::NPIX, A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, NA = T::NA, NTAPS = T::NTAPS;
+  constexpr int NPIECE = T::NPIECE, NU = T::NU;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;
+  char* const Bs = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int zo = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = p.Hout * p.Wout;
+  int m0 = 0, oy0 = 0, ox0 = 0;
+  if (KS == 1) {
+    m0 = blockIdx.x * BM;
+  } else {
+    const int tiles_x = (p.Wout + PW - 1) / PW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    oy0 = ty * T::PH;
+    ox0 = tx * PW;
+  }
+  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
+  const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo : nullptr;
+  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
+  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
+  const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
+  const int Cin = p.Cin, Cout = p.Cout, c0 = p.c0;
+
+  // ---- A staging map: work item u = (pixel, 8-channel half); NT is even so the half is per-thread constant ----
+  const int hf = tid & 1;
+  int aoff[NA];   // source pixel index, -1 = zero padding, -2 = no work item
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tid + i * NT;
+    const int pix = u >> 1;
+    int off = -2;
+    if (u < NU) {
+      if (KS == 1) {
+        const int m = m0 + pix;
+        off = (m < HWo) ? m : -1;
+      } else {
+        const int iy = pix / TW, ix = pix - iy * TW;
+        const int gy = oy0 * STRIDE - p.pad + iy, gx = ox0 * STRIDE - p.pad + ix;
+        const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
+        off = (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
+      }
+    }
+    aoff[i] = off;
+  }
+
+  float4 areg[NA][2];
+  float4 sreg[4];   // scale[8], shift[8] of this thread's channels in the chunk being staged
+
+  auto gload_A = [&](int chunk) {
+    const int c = chunk * XKC + hf * 8;
+    if (VEC) {
+      if (ps) {
+        sreg[0] = *reinterpret_cast<const float4*>(ps + c);
+        sreg[1] = *reinterpret_cast<const float4*>(ps + c + 4);
+        sreg[2] = *reinterpret_cast<const float4*>(psh + c);
+        sreg[3] = *reinterpret_cast<const float4*>(psh + c + 4);
+      }
+      // the whole chunk lies in one source (c0 % 16 == 0): block-uniform select
+      const bool second = (chunk * XKC >= c0);
+      const float* __restrict__ base = second ? a1 + (c - c0) : a0 + c;
+      const int ld = second ? p.lda1 : p.lda0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        const int sp = aoff[i];
+        if (sp >= 0) {
+          const float* src = base + (long long)sp * ld;
+          v0 = *reinterpret_cast<const float4*>(src);
+          v1 = *reinterpret_cast<const float4*>(src + 4);
+        }
+        areg[i][0] = v0;
+        areg[i][1] = v1;
+      }
+    } else {
+      if (ps) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          t[j] = (c + j < Cin) ? ps[c + j] : 1.f;
+          t[8 + j] = (c + j < Cin) ? psh[c + j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sreg[q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        float t[8];
+        const int sp = aoff[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c + j;
+          t[j] = (sp >= 0 && cc < Cin) ? ((cc < c0) ? a0[(long long)sp * p.lda0 + cc] : a1[(long long)sp * p.lda1 + (cc - c0)])
+                                      : 0.f;
+        }
+        areg[i][0] = make_float4(t[0], t[1], t[2], t[3]);
+        areg[i][1] = make_float4(t[4], t[5], t[6], t[7]);
+      }
+    }
+  };
+
+  auto write_A = [&](int chunk, int buf) {
+    const int c = chunk * XKC + hf * 8;
+    const float sc[8] = {sreg[0].x, sreg[0].y, sreg[0].z, sreg[0].w, sreg[1].x, sreg[1].y, sreg[1].z, sreg[1].w};
+    const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (aoff[i] == -2) continue;
+      float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
+                    areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      if (aoff[i] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = t[j];
+          if (ps) v = v * sc[j] + sh[j];
+          if (p.silu) v = silu_fast(v);
+          t[j] = (VEC || c + j < Cin) ? v : 0.f;
+        }
+      }
+      h8 hi, lo;
+      split8(t, hi, lo);
+      const int pix = (tid + i * NT) >> 1;
+      char* dst = As + buf * A_BYTES + (hf * NPIX + pix) * 16;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + 2 * NPIX * 16) = lo;
+    }
+  };
+
+  // B slice of K-step `step` = [4 units][cout_pad][8 f16] in HBM -> [4][BN][16 B] in LDS, 1 KiB per wave-instruction
+  auto issue_B = [&](int step, int buf) {
+#pragma unroll
+    for (int pc0 = 0; pc0 < NPIECE; pc0 += NW) {
+      const int pc = pc0 + wave;
+      if (pc < NPIECE) {
+        const int u = pc / (BN / 64), part = pc - u * (BN / 64);
+        const char* src = wpk + ((long long)(step * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
+        char* dst = Bs + buf * B_BYTES + (u * BN + part * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- MFMA operand addressing (v_mfma_f32_32x32x16_f16: lane l holds row l&31, k = 8*(l>>5)..+7 of A and of B) ----
+  const int kh = lane >> 5;
+  int apix[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = (wm * TM + tm) * 32 + (lane & 31);
+    if (KS == 1) {
+      apix[tm] = m;
+    } else {
+      const int py = m / PW, px = m - py * PW;
+      apix[tm] = (py * STRIDE) * TW + px * STRIDE;
+    }
+  }
+  const int boff = (kh * BN + wn * TN * 32 + (lane & 31)) * 16;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nchunks = (Cin + XKC - 1) / XKC;
+  const int nsteps = nchunks * NTAPS;
+
+  // ---- prologue: stage chunk 0 and the first weight slice ----
+  issue_B(0, 0);
+  gload_A(0);
+  write_A(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int chunk = 0, tap = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const bool more = (step + 1 < nsteps);
+    const bool first_tap = (tap == 0), last_tap = (tap == NTAPS - 1);
+    const bool next_a = (chunk + 1 < nchunks);
+    if (more) issue_B(step + 1, (step + 1) & 1);
+    if (first_tap && next_a) gload_A(chunk + 1);
+
+    {
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
+      const char* B = Bs + (step & 1) * B_BYTES + boff;
+      h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
+        al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
+        bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+    }
+
+    if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (++tap == NTAPS) { tap = 0; ++chunk; }
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+  const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
+  const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
+  const bool has_b = (p.bias != nullptr), has_c = (cadd != nullptr);
+  bool full = (n0 + BN <= Cout);
+  if (KS == 1) full = full && (m0 + BM <= HWo);
+  else full = full && (oy0 + T::PH <= p.Hout) && (ox0 + PW <= p.Wout);
+  if (full) {
+    // interior tile: no bounds checks; 16 residual loads in flight before the 16 stores of each 32x32 MFMA tile
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+      const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        int pixel[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          pixel[r] = (KS == 1) ? (m0 + m) : ((oy0 + m / PW) * p.Wout + ox0 + (m % PW));
+        }
+        float rv[16];
+        if (rz) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = rz[(long long)pixel[r] * p.ldr + n];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outz[(long long)pixel[r] * p.ldo + n] = (acc[tm][tn][r] * p.alpha + add) + rv[r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+    if (n >= Cout) continue;
+    const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        long long pixel;
+        bool ok;
+        if (KS == 1) {
+          pixel = m0 + m;
+          ok = pixel < HWo;
+        } else {
+          const int oy = oy0 + m / PW, ox = ox0 + (m % PW);
+          ok = (oy < p.Hout) && (ox < p.Wout);
+          pixel = (long long)oy * p.Wout + ox;
+        }
+        if (ok) {
+          const float v = acc[tm][tn][r] * p.alpha + add;
+          outz[pixel * p.ldo + n] = v + (rz ? rz[pixel * p.ldr + n] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+static bool is_vec(const GemmArgs& a) {
+  return (((a.c0 | a.c1 | a.lda0 | a.lda1 | a.Cin) & 15) == 0) && ((((uintptr_t)a.a0) | ((uintptr_t)a.a1)) & 15) == 0 &&
+         (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
+}
+
+template <class T, bool VEC>
+static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
+  int gx;
+  if (T::KS == 1) {
+    gx = (a.Hout * a.Wout + T::BM - 1) / T::BM;
+  } else {
+    gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
+  }
+  const int gy = (a.Cout + T::BN - 1) / T::BN;
+  dim3 grid(gx, gy, a.Z), block(T::NT);
+  static bool attr_set = false;
+  if (!attr_set && T::SMEM > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC>), grid, block, T::SMEM, s, a);
+  return hipGetLastError();
+}
+
+// tile ids of the f16x3 family (GemmArgs.tile / profile variant)
+static int auto_tile_x(const GemmArgs& a) {
+  if (a.stride == 2) return XT_64x128;
+  const long long M = (long long)a.Hout * a.Wout;
+  auto blocks = [&](int bm, int bn) {
+    long long mt;
+    if (a.ks == 1) {
+      mt = (M + bm - 1) / bm;
+    } else {
+      const int pw = bm >= 128 ? 16 : 8, ph = bm / pw;
+      mt = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
+    }
+    return mt * ((a.Cout + bn - 1) / bn) * a.Z;
+  };
+  if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
+  if (M >= 256 && blocks(256, 128) >= 512) return XT_256x128;
+  if (M >= 128 && blocks(128, 128) >= 384) return XT_128x128;
+  if (blocks(64, 128) >= 256) return XT_64x128;
+  return XT_64x64;
+}
+
+int gemm_resolve_tile_x(const GemmArgs& a) {
+  if (a.stride == 2) return XT_64x128;
+  return a.tile ? a.tile : auto_tile_x(a);
+}
+
+hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
+  if (!a.wpk || a.bT || a.ZI > 1 || a.cout_pad < ((a.Cout + 127) / 128) * 128) return hipErrorInvalidValue;
+  if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;
+  if (a.ks == 1 && (a.stride != 1 || a.ups)) return hipErrorInvalidValue;
+  const int tile = gemm_resolve_tile_x(a);
+  using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1>;
+  using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1>;
+  using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1>;
+  using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1>;
+  using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1>;
+  using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2>;
+  using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1>;
+  using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1>;
+  using X64x128_1 = XCfg<2, 2, 1, 2, 1, 1>;
+  using X64x64_1 = XCfg<2, 2, 1, 1, 1, 1>;
+  using X256x64_1 = XCfg<4, 1, 2, 2, 1, 1>;
+  if (!is_vec(a)) {   // ragged channel counts (conv_in: Cin = 3): scalar-gather staging, two tile shapes per kernel size
+    if (a.stride == 2) return launch_x<X64x128_3s2, false>(a, s);
+    const bool big = (tile == XT_256x128 || tile == XT_128x128 || tile == XT_256x64);
+    if (a.ks == 3) return big ? launch_x<X256x128_3, false>(a, s) : launch_x<X64x128_3, false>(a, s);
+    return big ? launch_x<X256x128_1, false>(a, s) : launch_x<X64x128_1, false>(a, s);
+  }
+  if (a.ks == 3) {
+    if (a.stride == 2) return launch_x<X64x128_3s2, true>(a, s);
+    switch (tile) {
+      case XT_256x128: return launch_x<X256x128_3, true>(a, s);
+      case XT_128x128: return launch_x<X128x128_3, true>(a, s);
+      case XT_64x128: return launch_x<X64x128_3, true>(a, s);
+      case XT_64x64: return launch_x<X64x64_3, true>(a, s);
+      case XT_256x64: return launch_x<X256x64_3, true>(a, s);
+    }
+  } else {
+    switch (tile) {
+      case XT_256x128: return launch_x<X256x128_1, true>(a, s);
+      case XT_128x128: return launch_x<X128x128_1, true>(a, s);
+      case XT_64x128: return launch_x<X64x128_1, true>(a, s);
+      case XT_64x64: return launch_x<X64x64_1, true>(a, s);
+      case XT_256x64: return launch_x<X256x64_1, true>(a, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing (device side, run once per parameter upload): PyTorch conv weight [Cout][Cin][k][k] fp32 ->
+// [step = chunk*k*k + tap][unit u][cout_pad][8] f16, u = {hi k0-7, hi k8-15, lo k0-7, lo k8-15}, times `wscale`
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_f16x3_kernel(const float* w, _Float16* dst, int cout, int cin, int kk, int cout_pad, float wscale,
+                                  long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    long long r = i >> 3;
+    const int n = (int)(r % cout_pad);
+    r /= cout_pad;
+    const int u = (int)(r & 3);
+    const int step = (int)(r >> 2);
+    const int chunk = step / kk, tap = step - chunk * kk;
+    const int k = chunk * XKC + (u & 1) * 8 + j;
+    float v = 0.f;
+    if (n < cout && k < cin) v = w[((long long)n * cin + k) * kk + tap] * wscale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    dst[i] = (u < 2) ? h : l;
+  }
+}
+
+size_t f16x3_packed_halfs(int cout, int cin, int ks) {
+  const int nchunks = (cin + XKC - 1) / XKC, cout_pad = ((cout + 127) / 128) * 128;
+  return (size_t)nchunks * ks * ks * 4 * cout_pad * 8;
+}
+
+hipError_t launch_pack_f16x3(const float* w_dev, void* dst, int cout, int cin, int ks, float wscale, hipStream_t s) {
+  const int cout_pad = ((cout + 127) / 128) * 128;
+  const long long total = (long long)f16x3_packed_halfs(cout, cin, ks);
+  long long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(pack_f16x3_kernel, dim3((unsigned)b), dim3(256), 0, s, w_dev, reinterpret_cast<_Float16*>(dst), cout,
+                     cin, ks * ks, cout_pad, wscale, total);
+  return hipGetLastError();
+}
+
+float f16x3_act_scale() { return ACT_SCALE; }
+
+}  // namespace asyrp

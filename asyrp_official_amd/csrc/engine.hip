@@ -104,6 +104,9 @@ struct asyrp_engine {
   bool finalized = false;
 
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
+  struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; };
+  std::unordered_map<std::string, XW> xw;        // conv weight name -> f16x3 image (conv_f16x3.hip)
+  int math = MATH_F16X3;                         // cfg.conv_math
   size_t param_bytes = 0;
   std::unordered_map<std::string, int> tproj_off;   // ResnetBlock / DeltaBlock prefix -> column in tproj
   int tproj_total = 0;
@@ -245,6 +248,37 @@ int upload(asyrp_engine* e, const std::string& name, const std::vector<float>& v
 
 const std::vector<float>& hostp(asyrp_engine* e, const std::string& key) { return e->host[e->spec_idx.at(key)]; }
 
+// conv weight in PyTorch layout [Cout][Cin][k][k] -> f16 hi/lo image of conv_f16x3.hip, scaled by a power of two so
+// that max|w| lands in [1024, 2048) (keeps w_lo a normal f16 for weights down to 1e-4 of the largest one)
+int pack_x3(asyrp_engine* e, const std::string& name, const std::vector<float>& w, int cout, int cin, int k) {
+  float mx = 0.f;
+  for (float v : w) mx = std::max(mx, std::fabs(v));
+  float wscale = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx)));
+  asyrp_engine::XW x;
+  auto it = e->xw.find(name);
+  const size_t halfs = f16x3_packed_halfs(cout, cin, k);
+  if (it != e->xw.end() && it->second.halfs == halfs) {
+    x = it->second;
+  } else {
+    if (it != e->xw.end()) { (void)hipFree(it->second.p); e->param_bytes -= it->second.halfs * 2; }
+    HIPCHK(hipMalloc(&x.p, halfs * 2));
+    x.halfs = halfs;
+    e->param_bytes += halfs * 2;
+  }
+  x.wscale = wscale;
+  x.cout_pad = ((cout + 127) / 128) * 128;
+  float* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, std::max<size_t>(w.size(), 1) * sizeof(float)));
+  HIPCHK(hipMemcpy(tmp, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t le = launch_pack_f16x3(tmp, x.p, cout, cin, k, wscale, nullptr);
+  hipError_t se = hipDeviceSynchronize();
+  (void)hipFree(tmp);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "f16x3 weight packing failed for " + name);
+  e->xw[name] = x;
+  return 0;
+}
+
 // conv weight [Cout][Cin][k][k] -> GEMM B operand [k*k][Cin][Cout]
 std::vector<float> pack_conv(const std::vector<float>& w, int cout, int cin, int k) {
   std::vector<float> o((size_t)k * k * cin * cout);
@@ -277,7 +311,10 @@ void drop(Ctx& c, Act& a) {
   a.p = nullptr;
 }
 
-int variant_of(const GemmArgs& g) { return gemm_resolve_tile(g) * 1000 + g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0); }
+int variant_of(const GemmArgs& g) {
+  if (g.math == MATH_F16X3 && g.wpk) return 10000 + gemm_resolve_tile_x(g) * 1000 + g.ks * 100 + g.stride * 10;
+  return gemm_resolve_tile(g) * 1000 + g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0);
+}
 
 int run_gemm(Ctx& c, const GemmArgs& g) {
   asyrp_engine* e = c.e;
@@ -333,6 +370,15 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.alpha = 1.0f;
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
   g.ZI = 1; g.Z = c.B;
+  g.math = MATH_F32;
+  if (c.e->math == MATH_F16X3) {
+    auto it = c.e->xw.find(wname);
+    if (it == c.e->xw.end()) return fail(ASYRP_EKEY, "missing f16x3 weight image " + wname);
+    g.math = MATH_F16X3;
+    g.wpk = it->second.p;
+    g.cout_pad = it->second.cout_pad;
+    g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());   // both powers of two: exact
+  }
   return run_gemm(c, g);
 }
 
@@ -617,7 +663,7 @@ int ddim_apply(Ctx& c, const float* x, const Act& et, const Act& et_mod, const f
 // =====================================================================================================
 extern "C" {
 
-int asyrp_abi_version(void) { return 1; }
+int asyrp_abi_version(void) { return 2; }
 
 const char* asyrp_last_error(void) { return g_err.c_str(); }
 
@@ -631,6 +677,7 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
   asyrp_engine* e = new asyrp_engine();
   e->cfg = *cfg;
+  e->math = (cfg->conv_math == ASYRP_MATH_F32) ? MATH_F32 : MATH_F16X3;
   e->max_batch = max_batch;
   e->device = device;
   build_specs_ddpm(e);
@@ -648,6 +695,7 @@ void asyrp_destroy(asyrp_engine* e) {
     (void)hipDeviceSynchronize();
   }
   for (auto& kv : e->dev) (void)hipFree(kv.second);
+  for (auto& kv : e->xw) (void)hipFree(kv.second.p);
   if (e->d_freqs) (void)hipFree(e->d_freqs);
   if (e->d_t) (void)hipFree(e->d_t);
   for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -741,10 +789,19 @@ int asyrp_finalize_params(asyrp_engine* e) {
         }
         TRY(upload(e, ap + ".qkv.weight", w));
         TRY(upload(e, ap + ".qkv.bias", b));
+        if (e->math == MATH_F16X3) {
+          std::vector<float> w3((size_t)3 * cout * cin);   // [3C][Cin] = q|k|v rows, PyTorch conv layout
+          for (int t = 0; t < 3; ++t) {
+            const auto& wt = hostp(e, ap + names[t] + ".weight");
+            std::copy(wt.begin(), wt.end(), w3.begin() + (size_t)t * cout * cin);
+          }
+          TRY(pack_x3(e, ap + ".qkv.weight", w3, 3 * cout, cin, 1));
+        }
       } else if (ends_with(p, ".k") || ends_with(p, ".v")) {
         continue;
       } else {
         TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
+        if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
       }
     } else {
       const std::string p = s.key.substr(0, s.key.rfind('.'));
@@ -946,7 +1003,7 @@ __global__ void pack_conv_weight_kernel(const float* src, float* dst, int cout, 
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                     const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
                     const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,
-                    const float* residual, float* y, void* stream) {
+                    const float* residual, float* y, int conv_math, int tile, void* stream) {
   if (!x0 || !weight || !y || B < 1) return fail(ASYRP_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
@@ -998,6 +1055,22 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
   g.chan_add = chan_add; g.ld_chan_add = Cout;
   if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
   g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
+  g.math = MATH_F32;
+  g.tile = tile;
+  if (conv_math == ASYRP_MATH_F16X3) {
+    std::vector<float> hw((size_t)Cout * Cin * ksize * ksize);
+    HIPCHK(hipMemcpy(hw.data(), weight, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (float v : hw) mx = std::max(mx, std::fabs(v));
+    const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx))) : 1.f;
+    float* xp;
+    TRY(dalloc((f16x3_packed_halfs(Cout, Cin, ksize) + 1) / 2, &xp));
+    HIPCHK(launch_pack_f16x3(weight, xp, Cout, Cin, ksize, wscale, s));
+    g.math = MATH_F16X3;
+    g.wpk = xp;
+    g.cout_pad = ((Cout + 127) / 128) * 128;
+    g.alpha = 1.0f / (wscale * f16x3_act_scale());
+  }
   hipError_t le = launch_gemm(g, s);
   if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);
   hipError_t se = hipStreamSynchronize(s);

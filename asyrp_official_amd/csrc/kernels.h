@@ -26,13 +26,29 @@ struct GemmArgs {
   float alpha;
   float* out; int ldo; long long o_zo, o_zi;
   int ZI, Z;
-  int tile;                       // 0 = auto, else TILE_* id
+  int tile;                       // 0 = auto, else TILE_* / XT_* id
+  // f16x3 path (conv_f16x3.hip): weights pre-split/pre-packed by launch_pack_f16x3; alpha must carry
+  // 1/(weight scale * f16x3_act_scale())
+  int math;                       // MATH_F32 (v_mfma_f32_32x32x2_f32) or MATH_F16X3 (3 x v_mfma_f32_32x32x16_f16)
+  const void* wpk; int cout_pad;
 };
+
+enum { MATH_F16X3 = 0, MATH_F32 = 1 };
 
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-int gemm_resolve_tile(const GemmArgs& a);   // TILE_* the launcher will pick
+enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5 };
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
+hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s);
+int gemm_resolve_tile(const GemmArgs& a);     // TILE_* the fp32 launcher will pick
+int gemm_resolve_tile_x(const GemmArgs& a);   // XT_* the f16x3 launcher will pick
+// f16x3 weight image: [ceil(Cin/16)*ks*ks][4][roundup(Cout,128)][8] halfs
+size_t f16x3_packed_halfs(int cout, int cin, int ks);
+hipError_t launch_pack_f16x3(const float* w_dev /*[Cout][Cin][ks][ks]*/, void* dst, int cout, int cin, int ks,
+                             float wscale, hipStream_t s);
+float f16x3_act_scale();
 // algorithmic work of one launch (2*M*N*K flops; A read once + out written once + weights once)
 void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 

@@ -365,7 +365,11 @@ int gemm_resolve_tile(const GemmArgs& a) {
   return a.tile ? a.tile : auto_tile(a);
 }
 
-hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+  return (a.math == MATH_F16X3 && a.wpk) ? launch_gemm_f16x3(a, s) : launch_gemm_f32(a, s);
+}
+
+hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.ZI <= 0) a.ZI = 1;
   if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;

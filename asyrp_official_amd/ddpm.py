@@ -53,9 +53,10 @@ def _cfg_get(ns, name, default=None):
 
 
 class DDPM(nn.Module):
-    def __init__(self, config, max_batch=64):
+    def __init__(self, config, max_batch=64, conv_math="f16x3"):
         super().__init__()
         self.config = config
+        self.conv_math = conv_math      # "f16x3" (3 x f16 MFMA, fp32-equivalent, default) or "f32" (fp32 MFMA)
         m, d = _cfg_get(config, "model"), _cfg_get(config, "data")
         self.ch = int(_cfg_get(m, "ch"))
         self.out_ch = int(_cfg_get(m, "out_ch"))
@@ -119,7 +120,7 @@ class DDPM(nn.Module):
         return make_config(family=_lib.FAMILY_DDPM, resolution=self.resolution, in_channels=self.in_channels,
                            out_channels=self.out_ch, ch=self.ch, ch_mult=self.ch_mult,
                            num_res_blocks=self.num_res_blocks, attn_resolutions=self.attn_resolutions,
-                           n_delta=n_delta)
+                           n_delta=n_delta, conv_math=self.conv_math)
 
     def _drop_engine(self):
         if self._engine is not None:

@@ -9,7 +9,7 @@ from . import _lib
 
 
 def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channels, ch, ch_mult, num_res_blocks,
-                attn_resolutions, num_head_channels=0, n_delta=0):
+                attn_resolutions, num_head_channels=0, n_delta=0, conv_math="f16x3"):
     cfg = _lib.AsyrpConfig()
     cfg.family, cfg.resolution, cfg.in_channels, cfg.out_channels = family, resolution, in_channels, out_channels
     cfg.ch, cfg.n_levels, cfg.num_res_blocks = ch, len(ch_mult), num_res_blocks
@@ -19,6 +19,7 @@ def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channel
     for i, r in enumerate(attn_resolutions):
         cfg.attn_resolutions[i] = int(r)
     cfg.num_head_channels, cfg.n_delta = num_head_channels, n_delta
+    cfg.conv_math = _lib.CONV_MATH[conv_math] if isinstance(conv_math, str) else int(conv_math)
     return cfg
 
 
@@ -180,8 +181,13 @@ class Engine:
         _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(var), C.byref(ms), C.byref(n), C.byref(fl),
                                                C.byref(by), C.byref(ams), C.byref(afl)))
         v = var.value
-        tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(v // 1000, (0, 0, 0, 0))
+        fam, tid = v // 10000, (v // 1000) % 10
         ks, stride = (v // 100) % 10, (v // 10) % 10
-        name = "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
-        return dict(variant=v, kernel=name, ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value,
+        if fam == 1:
+            tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2)}.get(tid, (0,) * 4)
+            name = "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
+        else:
+            tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
+            name = "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
+        return dict(variant=v, family="f16x3" if fam == 1 else "f32", kernel=name, ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value,
                     all_ms=ams.value, all_flops=afl.value)

@@ -46,6 +46,12 @@ enum asyrp_family {
   ASYRP_FAMILY_IDDPM = 1 /* models/improved_ddpm/unet.py:437 UNetModel     — AFHQ, ImageNet, MetFaces */
 };
 
+/* Arithmetic of the implicit-GEMM convolutions.  Both are fp32-equivalent (same error class vs the reference's
+ * fp32 CPU path, ~1e-6 per UNet forward); they differ in which matrix-core instruction carries the products:
+ *   F16X3: operands split into two f16 terms, three v_mfma_f32_32x32x16_f16 per K-slice, fp32 accumulate (default)
+ *   F32:   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (1/16 the f16 MFMA rate) */
+enum asyrp_conv_math { ASYRP_MATH_F16X3 = 0, ASYRP_MATH_F32 = 1 };
+
 /* Hyper-parameters.  DDPM reads them from configs/<dataset>.yml `model:` (models/ddpm/diffusion.py:331-337);
  * iDDPM/ADM from the arch dicts (models/improved_ddpm/script_util.py:5-42). */
 typedef struct asyrp_config {
@@ -61,7 +67,8 @@ typedef struct asyrp_config {
   int32_t attn_resolutions[ASYRP_MAX_LEVELS]; /* spatial sizes at which attention runs (e.g. 16) */
   int32_t num_head_channels;      /* iDDPM: 64; DDPM: 0 = single head over all channels */
   int32_t n_delta;                /* number of DeltaBlocks layer_0..layer_{n-1} (setattr_layers) */
-  int32_t reserved[8];
+  int32_t conv_math;              /* enum asyrp_conv_math: how the conv / 1x1 GEMMs are evaluated */
+  int32_t reserved[7];
 } asyrp_config;
 
 typedef struct asyrp_engine asyrp_engine;
@@ -148,7 +155,9 @@ int64_t asyrp_device_bytes(const asyrp_engine* e);
 int asyrp_profile_enable(asyrp_engine* e, int on);
 /* After a device sync: statistics of the implicit-GEMM launches recorded since the last read.
  * The DOMINANT variant (largest accumulated time) is reported in full:
- *   *variant = tile*1000 + ksize*100 + stride*10 + transposedB   (tile: 1=128x128, 2=128x64, 3=64x64, 4=128x32),
+ *   *variant = family*10000 + tile*1000 + ksize*100 + stride*10 + transposedB
+ *     family 0 = igemm_f32 (tile: 1=128x128, 2=128x64, 3=64x64, 4=128x32),
+ *     family 1 = igemm_f16x3 (tile: 1=256x128, 2=128x128, 3=64x128, 4=64x64, 5=256x64),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */
@@ -160,11 +169,13 @@ int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launc
  *   x0 [B,C0,H,W] (+ optional x1 [B,C1,H,W] = channel concat), weight [Cout,C0+C1,k,k] (k = 1 or 3),
  *   stride 1 (pad k/2) or 2 (DDPM Downsample: pad right/bottom, models/ddpm/diffusion.py:103-107),
  *   upsample: nearest x2 before the conv (:84-85).
- *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0). */
+ *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0).
+ *   conv_math: enum asyrp_conv_math; tile: 0 = the launcher's own choice, else force one tile shape of that
+ *   kernel family (1..5) so every compiled variant can be parity-tested. */
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                     const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
                     const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,
-                    const float* residual, float* y, void* stream);
+                    const float* residual, float* y, int conv_math, int tile, void* stream);
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
  * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T]. */
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream);

@@ -16,7 +16,11 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def hip_conv(x0, w, b, *, x1=None, stride=1, upsample=False, gn=None, silu=False, chan_add=None, residual=None):
+MATHS = ("f16x3", "f32")
+
+
+def hip_conv(x0, w, b, *, x1=None, stride=1, upsample=False, gn=None, silu=False, chan_add=None, residual=None,
+             math="f16x3", tile=0):
     from asyrp_official_amd import _lib
     lib = _lib.load()
     dev = "cuda"
@@ -31,7 +35,7 @@ def hip_conv(x0, w, b, *, x1=None, stride=1, upsample=False, gn=None, silu=False
     y = torch.empty((B, Cout, Ho, Wo), device=dev)
     _lib.check(lib.asyrp_op_conv2d(0, _p(x0d), C0, _p(x1d), 0 if x1 is None else x1.shape[1], B, H, W, _p(wd), _p(bd),
                                    Cout, k, stride, int(upsample), _p(gw), _p(gb), 1e-6, int(silu), _p(cad), _p(rd),
-                                   _p(y), None))
+                                   _p(y), _lib.CONV_MATH[math], int(tile), None))
     torch.cuda.synchronize()
     return y.cpu()
 
@@ -68,28 +72,77 @@ TIGHT = dict(rtol=1e-4, atol=2e-5)
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(2, 32, 32, 16), (1, 128, 128, 32), (2, 64, 96, 8), (3, 32, 64, 24),
                                           (1, 256, 512, 8), (2, 3, 32, 16), (2, 32, 3, 16), (1, 96, 160, 20)])
-def test_conv3x3_plain(B, Cin, Cout, H):
+@pytest.mark.parametrize("math", MATHS)
+def test_conv3x3_plain(B, Cin, Cout, H, math):
     x, w, b = _mk(B, Cin, Cout, H, 3, f"c3.{B}.{Cin}.{Cout}.{H}")
-    assert_close(hip_conv(x, w, b), ref_conv(x, w, b), what="conv3x3", **TIGHT)
+    assert_close(hip_conv(x, w, b, math=math), ref_conv(x, w, b), what="conv3x3", **TIGHT)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("k", [1, 3])
+def test_f16x3_every_tile_shape(tile, k):
+    """Force each compiled tile shape of the f16x3 family (256x128, 128x128, 64x128, 64x64, 256x64) on a ragged problem:
+    40x24 pixels (partial tiles on both axes), 64+32 concatenated channels, 160 output channels (partial N tile)."""
+    B, H, W = 2, 40, 24
+    x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
+    x1 = hash_normal(f"tile.x1.{k}", (B, 32, H, W)) * 3.0
+    w = hash_uniform(f"tile.w.{k}", (160, 96, k, k), -1, 1) / (96 * k * k) ** 0.5
+    b = 0.1 * hash_uniform(f"tile.b.{k}", (160,))
+    res = hash_normal(f"tile.r.{k}", (B, 160, H, W))
+    ca = hash_normal(f"tile.ca.{k}", (B, 160))
+    gn = (1 + 0.1 * hash_uniform("tile.g", (96,)), 0.1 * hash_uniform("tile.be", (96,)))
+
+    def run(**kw):
+        from asyrp_official_amd import _lib
+        lib = _lib.load()
+        d = lambda t: t.cuda().contiguous()
+        y = torch.empty((B, 160, H, W), device="cuda")
+        a0, a1, wd, bd, g0, g1, cad, rd = map(d, (x0, x1, w, b, gn[0], gn[1], ca, res))
+        _lib.check(lib.asyrp_op_conv2d(0, _p(a0), 64, _p(a1), 32, B, H, W, _p(wd), _p(bd), 160, k, 1, 0, _p(g0), _p(g1),
+                                       1e-6, 1, _p(cad), _p(rd), _p(y), _lib.MATH_F16X3, tile, None))
+        torch.cuda.synchronize()
+        return y.cpu()
+
+    x = torch.cat([x0, x1], 1)
+    x = F.group_norm(x, 32, gn[0], gn[1], eps=1e-6)
+    x = x * torch.sigmoid(x)
+    want = res + F.conv2d(x, w, b, padding=k // 2) + ca[:, :, None, None]
+    assert_close(run(), want, what=f"tile {tile} k={k}", **TIGHT)
+
+
+def test_f16x3_wide_dynamic_range():
+    """Operands spanning many binades (weights 1e-4..1, activations 1e-3..1e2): the two-term f16 split with
+    power-of-two pre-scaling must stay fp32-equivalent (no f16 subnormal/overflow loss)."""
+    B, C, H = 1, 64, 16
+    mag_x = 10.0 ** (hash_uniform("dr.mx", (B, C, H, H), -3, 2))
+    x = hash_normal("dr.x", (B, C, H, H)) * mag_x
+    mag_w = 10.0 ** (hash_uniform("dr.mw", (C, C, 3, 3), -4, 0))
+    w = hash_uniform("dr.w", (C, C, 3, 3), -1, 1) * mag_w / 24.0
+    b = torch.zeros(C)
+    got, want = hip_conv(x, w, b, math="f16x3"), ref_conv(x.double(), w.double(), b.double()).float()
+    assert_close(got, want, what="wide range", rtol=1e-4, atol=1e-5 * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(2, 32, 64, 16), (1, 256, 128, 32), (2, 64, 64, 8), (1, 512, 1536, 8)])
-def test_conv1x1(B, Cin, Cout, H):
+@pytest.mark.parametrize("math", MATHS)
+def test_conv1x1(B, Cin, Cout, H, math):
     x, w, b = _mk(B, Cin, Cout, H, 1, f"c1.{B}.{Cin}.{Cout}.{H}")
-    assert_close(hip_conv(x, w, b), ref_conv(x, w, b), what="conv1x1", **TIGHT)
+    assert_close(hip_conv(x, w, b, math=math), ref_conv(x, w, b), what="conv1x1", **TIGHT)
 
 
-def test_conv3x3_gn_silu_prologue_and_epilogue():
+@pytest.mark.parametrize("math", MATHS)
+def test_conv3x3_gn_silu_prologue_and_epilogue(math):
     B, Cin, Cout, H = 2, 64, 32, 16
     x, w, b = _mk(B, Cin, Cout, H, 3, "fused")
     gn = (1 + 0.1 * hash_uniform("fused.g", (Cin,)), 0.1 * hash_uniform("fused.be", (Cin,)))
     ca = hash_normal("fused.ca", (B, Cout))
     res = hash_normal("fused.res", (B, Cout, H, H))
     kw = dict(gn=gn, silu=True, chan_add=ca, residual=res)
-    assert_close(hip_conv(x, w, b, **kw), ref_conv(x, w, b, **kw), what="fused resblock conv", **TIGHT)
+    assert_close(hip_conv(x, w, b, math=math, **kw), ref_conv(x, w, b, **kw), what="fused resblock conv", **TIGHT)
 
 
-def test_conv3x3_concat_two_sources_group_straddle():
+@pytest.mark.parametrize("math", MATHS)
+def test_conv3x3_concat_two_sources_group_straddle(math):
     # 64 + 32 = 96 channels -> 3 per group: groups straddle the two sources (like 512+256 in up.4)
     B, H = 2, 16
     x0 = hash_normal("cat.x0", (B, 64, H, H)) + 0.5
@@ -97,26 +150,30 @@ def test_conv3x3_concat_two_sources_group_straddle():
     _, w, b = _mk(B, 96, 64, H, 3, "cat")
     gn = (1 + 0.1 * hash_uniform("cat.g", (96,)), 0.1 * hash_uniform("cat.be", (96,)))
     kw = dict(x1=x1, gn=gn, silu=True)
-    assert_close(hip_conv(x0, w, b, **kw), ref_conv(x0, w, b, **kw), what="concat conv", **TIGHT)
+    assert_close(hip_conv(x0, w, b, math=math, **kw), ref_conv(x0, w, b, **kw), what="concat conv", **TIGHT)
 
 
-def test_conv3x3_stride2_asymmetric_pad():
+@pytest.mark.parametrize("math", MATHS)
+def test_conv3x3_stride2_asymmetric_pad(math):
     for (B, C, H) in [(2, 32, 16), (1, 128, 32), (1, 64, 8)]:
         x, w, b = _mk(B, C, C, H, 3, f"s2.{C}.{H}")
-        assert_close(hip_conv(x, w, b, stride=2), ref_conv(x, w, b, stride=2), what="downsample conv", **TIGHT)
+        assert_close(hip_conv(x, w, b, stride=2, math=math), ref_conv(x, w, b, stride=2), what="downsample conv", **TIGHT)
 
 
-def test_conv3x3_nearest_upsample():
+@pytest.mark.parametrize("math", MATHS)
+def test_conv3x3_nearest_upsample(math):
     for (B, C, H) in [(2, 32, 8), (1, 64, 16), (1, 128, 4)]:
         x, w, b = _mk(B, C, C, H, 3, f"up.{C}.{H}")
-        assert_close(hip_conv(x, w, b, upsample=True), ref_conv(x, w, b, upsample=True), what="upsample conv", **TIGHT)
+        assert_close(hip_conv(x, w, b, upsample=True, math=math), ref_conv(x, w, b, upsample=True), what="upsample conv",
+                     **TIGHT)
 
 
-def test_gn_without_silu_is_the_attention_norm():
+@pytest.mark.parametrize("math", MATHS)
+def test_gn_without_silu_is_the_attention_norm(math):
     B, C, H = 2, 64, 8
     x, w, b = _mk(B, C, 3 * C, H, 1, "qkv")
     gn = (1 + 0.1 * hash_uniform("qkv.g", (C,)), 0.1 * hash_uniform("qkv.be", (C,)))
-    assert_close(hip_conv(x, w, b, gn=gn), ref_conv(x, w, b, gn=gn), what="qkv conv", **TIGHT)
+    assert_close(hip_conv(x, w, b, gn=gn, math=math), ref_conv(x, w, b, gn=gn), what="qkv conv", **TIGHT)
 
 
 def test_gn_large_mean_offset_is_stable():

@@ -11,10 +11,10 @@ from util_models import err_stats, hip_model, synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def small():
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def small(request):
     sd = synthetic(SMALL, 2, seed=7)
-    return hip_model(SMALL, sd, 2), sd, hash_normal("small.x", (2, 3, 32, 32), seed=1)
+    return hip_model(SMALL, sd, 2, conv_math=request.param), sd, hash_normal("small.x", (2, 3, 32, 32), seed=1)
 
 
 def test_small_forward_single(small, golden_small):
@@ -69,16 +69,17 @@ def test_cpu_input_fails_loudly(small):
         m(x, torch.ones(2) * 701.0)
 
 
-def test_celeba_full_size_forward(golden_celeba):
+@pytest.mark.parametrize("conv_math", ["f16x3", "f32"])
+def test_celeba_full_size_forward(golden_celeba, conv_math):
     """CelebA-HQ DDPM 256x256 (114 M params), B=1: vs the reference fixture AND the oracle run here."""
     sd = synthetic(CELEBA, 1, seed=1234)
-    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    m = hip_model(CELEBA, sd, 1, max_batch=2, conv_math=conv_math)
     x = hash_normal("celeba.x", (1, 3, 256, 256), seed=1234)
     t = torch.ones(1) * 768.0
     et, em, dh, mh = m(x.cuda(), t.cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
     g = golden_celeba
     for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh)):
-        print(name, err_stats(got, g[name]))
+        print(conv_math, name, err_stats(got, g[name]))
         assert_close(got, g[name], what=name)
     et1, _, _, mh1 = m(x.cuda(), t.cuda())
     assert_close(et1, g["fwd_single.et"], what="single et")
