@@ -26,7 +26,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+# /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; f16/bf16 MFMA ~2500 TFLOP/s
+F32_MFMA_PEAK_TFLOPS = 157.3
+F16_MFMA_PEAK_TFLOPS = 2500.0
 T_EDIT, T_0, N_INV, N_GEN = 500, 999, 40, 40
 
 CELEBA = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16],
@@ -79,6 +81,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
+                    help="f16x3: 3 x f16 MFMA per product, fp32-equivalent (default); f32: fp32-input MFMA")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +104,7 @@ def main():
 
     B = a.batch
     torch.manual_seed(1234)                     # main.py:301 default seed
-    model = DDPM(celeba_namespace(), max_batch=B)
+    model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math)
     model.setattr_layers(1)                     # get_h_num = 1
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
@@ -149,15 +153,25 @@ def main():
             "metric": "edited images/sec, CelebA-HQ 256^2 40-step Asyrp, 1/2/4/8 GPU",
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
+            "dtype": "f32 (conv products on f16 MFMA as exact two-term splits, fp32 accumulate)" if a.conv_math == "f16x3"
+            else "f32", "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
             "config": {"workload": f"CelebA-HQ DDPM 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
                                    f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
                        "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)"},
         }
         if prof and prof["launches"]:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": prof["kernel"],
+            if prof["family"] == "f16x3":
+                # the kernel issues 3 f16 matrix products per algorithmic (fp32-equivalent) product: its ceiling for
+                # ALGORITHMIC flops is the dense f16 MFMA peak / 3
+                peak = F16_MFMA_PEAK_TFLOPS / 3.0
+                basis = ("dense f16 MFMA 2500 TFLOP/s / 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent product "
+                         "(two-term f16 operand split)")
+            else:
+                peak, basis = F32_MFMA_PEAK_TFLOPS, "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "peak_basis": basis,
+                               "x_fp32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS, "kernel": prof["kernel"],
                                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / prof["launches"],
                                "flops_per_launch": prof["flops"] / prof["launches"],
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,

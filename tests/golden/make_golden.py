@@ -127,10 +127,23 @@ def run_celeba(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_checkpoint_keys(out):
+    """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
+    import json
+    res = {}
+    for f in ("smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"):
+        sd = torch.load(os.path.join(REF, "checkpoint", f), map_location="cpu", weights_only=False)["0"]
+        res[f] = {k: list(v.shape) for k, v in sd.items()}
+    json.dump(res, open(out, "w"), indent=1)
+    print("wrote", out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys"], default=None)
     a = ap.parse_args()
+    if a.only in (None, "keys"):
+        run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
     if a.only in (None, "small"):
         run_small(os.path.join(HERE, "ddpm_small.npz"))
     if a.only in (None, "celeba"):

@@ -1,0 +1,132 @@
+"""CPU-side checks of the host logic and of the C-ABI surface (no compute calls: there is no GPU here)."""
+import json
+import os
+import re
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+from oracle.weights import CELEBA, SMALL, ddpm_param_shapes
+from util_models import namespace_for
+
+REF = os.environ.get("ASYRP_REFERENCE", "/root/reference")
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "asyrp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asyrp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    declared = _header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/asyrp.h but not exported by libasyrp_hip.so"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes signature table and include/asyrp.h disagree"
+    assert lib.asyrp_abi_version() == 2
+
+
+def test_engine_parameter_inventory_equals_reference_state_dict():
+    """asyrp_param_info lists exactly the reference's state_dict keys/shapes (pinned via the golden-checked oracle shapes)."""
+    from asyrp_official_amd.engine import make_config, param_specs
+    for cfg, nd in ((SMALL, 2), (CELEBA, 1)):
+        c = make_config(resolution=cfg.resolution, in_channels=cfg.in_channels, out_channels=cfg.out_ch, ch=cfg.ch,
+                        ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, attn_resolutions=cfg.attn_resolutions,
+                        n_delta=nd)
+        got = dict(param_specs(c))
+        want = {k: tuple(v) for k, v in ddpm_param_shapes(cfg, n_delta=nd).items()}
+        assert got == want
+
+
+def test_mirror_state_dict_roundtrip_and_delta_block_keys():
+    from asyrp_official_amd import DDPM
+    m = DDPM(namespace_for(SMALL), max_batch=2)
+    m.setattr_layers(1)
+    keys = set(m.state_dict().keys())
+    assert keys == set(ddpm_param_shapes(SMALL, n_delta=1).keys())
+    # key names of a shipped DeltaBlock checkpoint (fixture written by tests/golden/make_golden.py from checkpoint/*.pth)
+    fx = json.load(open(os.path.join(GOLDEN, "delta_checkpoint_keys.json")))
+    big = DDPM(namespace_for(CELEBA), max_batch=1)
+    big.setattr_layers(1)
+    layer = dict(big.layer_0.state_dict())
+    assert {k: list(v.shape) for k, v in layer.items()} == fx["smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth"]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "checkpoint")), reason="reference checkpoints not on this box")
+def test_shipped_delta_checkpoints_load_unmodified():
+    """Every DDPM-flavour checkpoint/*.pth["0"] loads into model.layer_0 exactly as diffusion_latent.py:674-676 does."""
+    from asyrp_official_amd import DDPM
+    m = DDPM(namespace_for(CELEBA), max_batch=1)
+    m.setattr_layers(1)
+    n = 0
+    for f in sorted(os.listdir(os.path.join(REF, "checkpoint"))):
+        sd = torch.load(os.path.join(REF, "checkpoint", f), map_location="cpu", weights_only=False)["0"]
+        if "conv1.weight" not in sd:      # iDDPM-flavour DeltaBlock (in_layers/out_layers keys): other UNet family
+            continue
+        res = m.layer_0.load_state_dict(sd)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert torch.equal(m.state_dict()["layer_0.conv2.weight"], sd["conv2.weight"])
+        n += 1
+    assert n >= 20
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    from asyrp_official_amd import AsyrpDeviceError, DDPM, denoising_step
+    m = DDPM(namespace_for(SMALL), max_batch=2)
+    x = torch.zeros(1, 3, 32, 32)
+    with pytest.raises(AsyrpDeviceError):
+        m(x, torch.ones(1) * 10.0)
+    with pytest.raises(AsyrpDeviceError):
+        denoising_step(x, torch.ones(1) * 10.0, torch.ones(1) * 5.0, models=m, logvars=None,
+                       b=torch.linspace(1e-4, 0.02, 1000))
+    with pytest.raises(NotImplementedError):
+        m(x, torch.ones(1), index=0, delta_h=torch.zeros(1, 64, 8, 8))
+
+
+def test_shard_bounds_cover_batch():
+    from asyrp_official_amd import shard_bounds
+    for n in (1, 5, 32, 33, 256):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_bounds(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from asyrp_official_amd.sampler import gather_shards, shard_bounds
+    full = torch.arange(n_total * 3 * 4 * 4, dtype=torch.float32).reshape(n_total, 3, 4, 4)
+    lo, hi = shard_bounds(n_total, world, rank)
+    local = full[lo:hi] * 2.0 + 1.0            # stand-in for "edit my images": any per-image function
+    got = gather_shards(local.contiguous(), n_total)
+    torch.save(got, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4, 5])
+def test_two_rank_gloo_shard_and_all_gather(tmp_path, n_total):
+    """The N>1 path: contiguous batch shards, no data-path collective, one all-gather (uneven shards padded)."""
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    full = torch.arange(n_total * 3 * 4 * 4, dtype=torch.float32).reshape(n_total, 3, 4, 4) * 2.0 + 1.0
+    for r in range(2):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"r{r}.pt")), full)
