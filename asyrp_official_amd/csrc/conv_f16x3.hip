@@ -50,7 +50,8 @@ struct XCfg {
   static constexpr int NTAPS = KS * KS;
   static constexpr int NPIECE = 4 * BN / 64;           // 1-KiB LDS-DMA pieces per B slice
   static constexpr size_t SMEM = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES;
-  static constexpr int MINW = (SMEM <= 76 * 1024) ? 2 : 1;   // workgroups per CU the LDS admits (=> waves per SIMD)
+  // workgroups per CU the LDS admits x waves per workgroup / 4 SIMDs = waves per SIMD to budget registers for
+  static constexpr int MINW = ((SMEM <= 76 * 1024) ? 2 : 1) * (NW / 4);
 };
 
 __device__ __forceinline__ float silu_fast(float v) {
@@ -72,12 +73,19 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 
 // VEC: Cin, c0, c1 and both row strides are multiples of 16 floats and the bases 16-B aligned (every layer but
 // conv_in): a K-chunk is 16 contiguous floats of ONE source per pixel -> two global_load_dwordx4 per work item.
-template <class T, bool VEC>
+// ABL: profiling-only instantiation whose phases can be switched off at run time through p.abl (timing ablations;
+//      results are then wrong by construction): 1 = no staging math, 2 = no weight LDS-DMA in the loop, 4 = no MFMA,
+//      8 = no activation loads/writes in the loop, 16 = no per-step wait+barrier.
+template <class T, bool VEC, bool ABL = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
+  const int abl = ABL ? p.abl : 0;
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, PW = T::PW, TW = T::TW;
   constexpr int NPIX = T::NPIX, A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, NA = T::NA, NTAPS = T::NTAPS;
   constexpr int NPIECE = T::NPIECE, NU = T::NU;
+  // 8-wave workgroups run 4 waves per SIMD inside a 128-VGPR budget: activation loads are issued right before their
+  // staging pass (not a chunk ahead) and fragments are fetched per MFMA pass; the other three waves hide the latency.
+  constexpr bool LOWREG = (NW >= 8);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       if (aoff[i] == -2) continue;
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
-      if (aoff[i] >= 0) {
+      if (aoff[i] >= 0 && !(abl & 1)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float v = t[j];
@@ -262,44 +270,84 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     const bool more = (step + 1 < nsteps);
     const bool first_tap = (tap == 0), last_tap = (tap == NTAPS - 1);
     const bool next_a = (chunk + 1 < nchunks);
-    if (more) issue_B(step + 1, (step + 1) & 1);
-    if (first_tap && next_a) gload_A(chunk + 1);
+    if (more && !(abl & 2)) issue_B(step + 1, (step + 1) & 1);
+    if (!LOWREG && first_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
 
     {
       const int ky = tap / KS, kx = tap - ky * KS;
       const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
       const char* B = Bs + (step & 1) * B_BYTES + boff;
-      h8 ah[TM], al[TM], bh[TN], bl[TN];
+      // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) is the same in every variant: results are bit-identical across tiles
+      if (LOWREG) {
+        h8 fa[TM], fb[TN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
-        al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+        for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);   // x_lo
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);                    // w_hi
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);                   // x_hi
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);      // w_lo
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+      } else {
+        h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
+          al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
+          bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
+        }
+        if (ABL && (abl & 4)) {   // keep the fragment reads alive, drop the matrix work
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(ah[tm]), "v"(al[tm]));
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bh[tn]), "v"(bl[tn]));
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
-        bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
     }
 
-    if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (last_tap && next_a && !(abl & 8)) {
+      if (LOWREG) gload_A(chunk + 1);
+      write_A(chunk + 1, (chunk + 1) & 1);
+    }
+    if (!(abl & 16)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     if (++tap == NTAPS) { tap = 0; ++chunk; }
   }
 
@@ -311,58 +359,103 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   bool full = (n0 + BN <= Cout);
   if (KS == 1) full = full && (m0 + BM <= HWo);
   else full = full && (oy0 + T::PH <= p.Hout) && (ox0 + PW <= p.Wout);
+  // GroupNorm statistics of the tensor being written (sum, sum of squares per output channel over this workgroup's
+  // pixels), for the NEXT layer's normalisation: accumulated in double, reduced in a fixed order (deterministic,
+  // batch-invariant), written as one partial per (image, M-block, channel).  LDS is free after the last K-step barrier.
+  double* const red = reinterpret_cast<double*>(smem);   // [WM][BN][2]
+  const bool want_stats = (p.stats != nullptr);
+  auto stat_commit = [&](int tn, double s1, double s2) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (kh == 0) {
+      double* d = red + ((size_t)wm * BN + (wn * TN + tn) * 32 + (lane & 31)) * 2;
+      d[0] = s1;
+      d[1] = s2;
+    }
+  };
   if (full) {
-    // interior tile: no bounds checks; 16 residual loads in flight before the 16 stores of each 32x32 MFMA tile
+    // interior tile: no bounds checks
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
       const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
-        int pixel[16];
+        // 8 rows at a time (8 residual loads in flight, then 8 stores); 32-bit element offsets from the per-image
+        // base (an image is < 2^31 elements): saddr + voffset addressing, one VGPR per address
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          int pixel[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = half * 8 + q;
+            const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pixel[q] = (KS == 1) ? (m0 + m) : ((oy0 + m / PW) * p.Wout + ox0 + (m % PW));
+          }
+          float rv[8];
+          if (rz) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = rz[pixel[q] * p.ldr + n];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float v = (acc[tm][tn][half * 8 + q] * p.alpha + add) + rv[q];
+            outz[pixel[q] * p.ldo + n] = v;
+            if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+          }
+        }
+      }
+      if (want_stats) stat_commit(tn, s1, s2);
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+      const bool nok = (n < Cout);
+      const float add = nok ? ((has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f)) : 0.f;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          pixel[r] = (KS == 1) ? (m0 + m) : ((oy0 + m / PW) * p.Wout + ox0 + (m % PW));
+          int pixel;
+          bool ok;
+          if (KS == 1) {
+            pixel = m0 + m;
+            ok = pixel < HWo;
+          } else {
+            const int oy = oy0 + m / PW, ox = ox0 + (m % PW);
+            ok = (oy < p.Hout) && (ox < p.Wout);
+            pixel = oy * p.Wout + ox;
+          }
+          if (ok && nok) {
+            const float v = (acc[tm][tn][r] * p.alpha + add) + (rz ? rz[pixel * p.ldr + n] : 0.f);
+            outz[pixel * p.ldo + n] = v;
+            if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+          }
         }
-        float rv[16];
-        if (rz) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rz[(long long)pixel[r] * p.ldr + n];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) outz[(long long)pixel[r] * p.ldo + n] = (acc[tm][tn][r] * p.alpha + add) + rv[r];
       }
+      if (want_stats) stat_commit(tn, s1, s2);
     }
-    return;
   }
+  if (want_stats) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      if (n0 + c < Cout) {
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
-    if (n >= Cout) continue;
-    const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        long long pixel;
-        bool ok;
-        if (KS == 1) {
-          pixel = m0 + m;
-          ok = pixel < HWo;
-        } else {
-          const int oy = oy0 + m / PW, ox = ox0 + (m % PW);
-          ok = (oy < p.Hout) && (ox < p.Wout);
-          pixel = (long long)oy * p.Wout + ox;
+        for (int w = 0; w < T::WM; ++w) {
+          s1 += red[((size_t)w * BN + c) * 2];
+          s2 += red[((size_t)w * BN + c) * 2 + 1];
         }
-        if (ok) {
-          const float v = acc[tm][tn][r] * p.alpha + add;
-          outz[pixel * p.ldo + n] = v + (rz ? rz[pixel * p.ldr + n] : 0.f);
-        }
+        double* dst = p.stats + (((size_t)zo * gridDim.x + blockIdx.x) * Cout + n0 + c) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
       }
     }
   }
@@ -373,7 +466,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC>
+template <class T, bool VEC, bool ABL = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -385,12 +478,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -420,16 +513,37 @@ int gemm_resolve_tile_x(const GemmArgs& a) {
   return a.tile ? a.tile : auto_tile_x(a);
 }
 
+// the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
+static int eff_tile_x(const GemmArgs& a) {
+  if (a.stride == 2) return XT_64x128;
+  const int t = gemm_resolve_tile_x(a);
+  if (is_vec(a)) return t;
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8) ? XT_256x128 : XT_64x128;
+}
+
+int gemm_mblocks(const GemmArgs& a) {
+  int bm;
+  switch (eff_tile_x(a)) {
+    case XT_256x128: case XT_256x64: case XT_256x128W8: bm = 256; break;
+    case XT_128x128: bm = 128; break;
+    default: bm = 64;
+  }
+  if (a.ks == 1) return (a.Hout * a.Wout + bm - 1) / bm;
+  const int pw = bm >= 128 ? 16 : 8, ph = bm / pw;
+  return ((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
+}
+
 hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   if (!a.wpk || a.bT || a.ZI > 1 || a.cout_pad < ((a.Cout + 127) / 128) * 128) return hipErrorInvalidValue;
   if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;
   if (a.ks == 1 && (a.stride != 1 || a.ups)) return hipErrorInvalidValue;
-  const int tile = gemm_resolve_tile_x(a);
+  const int tile = eff_tile_x(a);
   using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1>;
   using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1>;
   using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1>;
   using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1>;
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1>;
+  using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2>;
   using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1>;
   using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1>;
@@ -438,9 +552,13 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X256x64_1 = XCfg<4, 1, 2, 2, 1, 1>;
   if (!is_vec(a)) {   // ragged channel counts (conv_in: Cin = 3): scalar-gather staging, two tile shapes per kernel size
     if (a.stride == 2) return launch_x<X64x128_3s2, false>(a, s);
-    const bool big = (tile == XT_256x128 || tile == XT_128x128 || tile == XT_256x64);
+    const bool big = (tile == XT_256x128);
     if (a.ks == 3) return big ? launch_x<X256x128_3, false>(a, s) : launch_x<X64x128_3, false>(a, s);
     return big ? launch_x<X256x128_1, false>(a, s) : launch_x<X64x128_1, false>(a, s);
+  }
+  if (a.abl) {   // profiling build of the main tile only
+    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3, true, true>(a, s);
+    return hipErrorInvalidValue;
   }
   if (a.ks == 3) {
     if (a.stride == 2) return launch_x<X64x128_3s2, true>(a, s);
@@ -450,6 +568,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_64x128: return launch_x<X64x128_3, true>(a, s);
       case XT_64x64: return launch_x<X64x64_3, true>(a, s);
       case XT_256x64: return launch_x<X256x64_3, true>(a, s);
+      case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
     }
   } else {
     switch (tile) {

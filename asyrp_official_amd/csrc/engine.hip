@@ -83,6 +83,9 @@ struct Pool {
 struct Act {
   float* p = nullptr;
   int C = 0, H = 0, W = 0;
+  // GroupNorm partial statistics written by the producing conv's epilogue ([B][st_nblk][C][2] doubles), or null
+  double* st = nullptr;
+  int st_nblk = 0;
   long long per_image() const { return (long long)H * W * C; }
 };
 
@@ -308,7 +311,9 @@ int new_act(Ctx& c, int C, int H, int W, Act* a) {
 }
 void drop(Ctx& c, Act& a) {
   c.e->pool.put(a.p);
+  if (a.st) c.e->pool.put(reinterpret_cast<float*>(a.st));
   a.p = nullptr;
+  a.st = nullptr;
 }
 
 int variant_of(const GemmArgs& g) {
@@ -345,7 +350,7 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
-         const Act* resid, Act* out) {
+         const Act* resid, Act* out, bool want_stats = false) {
   const int Hin = x0.H, Win = x0.W;
   int Ho = Hin, Wo = Win;
   if (ups) { Ho *= 2; Wo *= 2; }
@@ -378,31 +383,52 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     g.wpk = it->second.p;
     g.cout_pad = it->second.cout_pad;
     g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());   // both powers of two: exact
+    if (want_stats) {   // the output will be group-normalised: its statistics come out of this launch's epilogue
+      out->st_nblk = gemm_mblocks(g);
+      float* sp = nullptr;
+      TRY(c.e->pool.get((size_t)c.B * out->st_nblk * Cout * 4, &sp));
+      out->st = reinterpret_cast<double*>(sp);
+      g.stats = out->st;
+    }
   }
   return run_gemm(c, g);
 }
 
-// GroupNorm(32, eps) statistics of (x0|x1) -> scale/shift [B][C] (pool buffers returned to the caller)
+// GroupNorm(32, eps) of the virtual concat (x0|x1) -> scale/shift [B][C] (pool buffers returned to the caller).
+// Per-channel partial statistics come from the producing conv's epilogue when it wrote them (Act::st); a tensor without
+// them (h-space mix output, fp32-MFMA mode) gets one standalone reduction pass.
 int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float eps, float** scale, float** shift) {
   const int C = x0.C + (x1 ? x1->C : 0);
   const int HW = x0.H * x0.W;
   TRY(c.e->pool.get((size_t)c.B * C, scale));
   TRY(c.e->pool.get((size_t)c.B * C, shift));
-  float* part = nullptr;
-  TRY(c.e->pool.get(gn_partial_doubles(c.B, C, HW) * 2, &part));
-  GnArgs a;
+  float* tmp[2] = {nullptr, nullptr};
+  GnFin2Args a;
   memset(&a, 0, sizeof a);
-  a.a0 = x0.p; a.c0 = x0.C; a.lda0 = x0.C; a.a0_z = x0.per_image();
-  if (x1) { a.a1 = x1->p; a.c1 = x1->C; a.lda1 = x1->C; a.a1_z = x1->per_image(); }
-  a.HW = HW; a.N = c.B; a.C = C;
+  const Act* src[2] = {&x0, x1};
+  for (int k = 0; k < 2; ++k) {
+    if (!src[k]) continue;
+    const double* st = src[k]->st;
+    int nblk = src[k]->st_nblk;
+    if (!st) {
+      nblk = gn_nblk_of(HW);
+      TRY(c.e->pool.get((size_t)c.B * nblk * src[k]->C * 4, &tmp[k]));
+      HIPCHK(launch_gn_partial(src[k]->p, src[k]->C, src[k]->per_image(), HW, c.B, src[k]->C,
+                               reinterpret_cast<double*>(tmp[k]), c.s));
+      st = reinterpret_cast<double*>(tmp[k]);
+    }
+    if (k == 0) { a.p0 = st; a.nblk0 = nblk; a.C0 = src[k]->C; }
+    else { a.p1 = st; a.nblk1 = nblk; a.C1 = src[k]->C; }
+  }
+  a.N = c.B; a.HW = HW;
   a.gamma = P(c, prefix + ".weight");
   a.beta = P(c, prefix + ".bias");
   if (!a.gamma || !a.beta) return fail(ASYRP_EKEY, "missing norm params " + prefix);
   a.eps = eps;
   a.scale = *scale; a.shift = *shift;
-  a.partial = reinterpret_cast<double*>(part);
-  HIPCHK(launch_gn(a, c.s));
-  c.e->pool.put(part);
+  HIPCHK(launch_gn_finalize2(a, c.s));
+  for (int k = 0; k < 2; ++k)
+    if (tmp[k]) c.e->pool.put(tmp[k]);
   return 0;
 }
 
@@ -415,7 +441,7 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
   TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1));
   Act h1;
   TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
-           c.tproj + e->tproj_off.at(p), nullptr, &h1));
+           c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
   e->pool.put(sc1); e->pool.put(sh1);
   TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2));
   Act sc;
@@ -427,7 +453,7 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
   } else {
     sc = x0;   // identity shortcut never has a concat input
   }
-  TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sc, out));
+  TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sc, out, true));
   e->pool.put(sc2); e->pool.put(sh2);
   drop(c, h1);
   if (own_sc) drop(c, sc);
@@ -478,7 +504,7 @@ int attnblock(Ctx& c, const std::string& p, const Act& x, Act* out) {
   TRY(attention_core(c, qkv.p, x.C, x.H * x.W, 1, 1.0f / std::sqrt((float)x.C), o.p));
   drop(c, qkv);
   TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr,
-           &x, out));
+           &x, out, true));
   drop(c, o);
   return 0;
 }
@@ -487,7 +513,7 @@ int attnblock(Ctx& c, const std::string& p, const Act& x, Act* out) {
 int deltablock(Ctx& c, const std::string& p, const Act& h, bool use_temb, Act* out) {
   Act d1;
   TRY(conv(c, h, nullptr, p + ".conv1.weight", p + ".conv1.bias", h.C, 1, 1, 0, nullptr, nullptr, 0,
-           use_temb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1));
+           use_temb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1, true));
   float *sc, *sh;
   TRY(gn(c, d1, nullptr, p + ".norm2", 1e-6f, &sc, &sh));
   TRY(conv(c, d1, nullptr, p + ".conv2.weight", p + ".conv2.bias", h.C, 1, 1, 0, sc, sh, 1, nullptr, nullptr, out));
@@ -523,7 +549,7 @@ int decoder(Ctx& c, const Act& hin, const std::vector<Act>& skips, Act* eps) {
     if (i != 0) {
       Act o;
       TRY(conv(c, h, nullptr, S("up.%d.upsample.conv.weight", i), S("up.%d.upsample.conv.bias", i), h.C, 3, 1, 1,
-               nullptr, nullptr, 0, nullptr, nullptr, &o));
+               nullptr, nullptr, 0, nullptr, nullptr, &o, true));
       replace(o);
       res *= 2;
     }
@@ -566,7 +592,7 @@ int unet_core(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int ap
   {
     Act h0;
     TRY(conv(c, xin, nullptr, "conv_in.weight", "conv_in.bias", cf.ch, 3, 1, 0, nullptr, nullptr, 0, nullptr, nullptr,
-             &h0));
+             &h0, true));
     skips.push_back(h0);
   }
   int res = R;
@@ -585,7 +611,7 @@ int unet_core(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int ap
     if (i != L - 1) {
       Act o;
       TRY(conv(c, skips.back(), nullptr, S("down.%d.downsample.conv.weight", i), S("down.%d.downsample.conv.bias", i),
-               skips.back().C, 3, 2, 0, nullptr, nullptr, 0, nullptr, nullptr, &o));
+               skips.back().C, 3, 2, 0, nullptr, nullptr, 0, nullptr, nullptr, &o, true));
       skips.push_back(o);
       res /= 2;
     }
@@ -1077,6 +1103,136 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
   for (void* p : tmp) (void)hipFree(p);
   if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv launch: ") + hipGetErrorString(le));
   if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv sync: ") + hipGetErrorString(se));
+  return 0;
+}
+
+// conv (f16x3) with the fused GroupNorm-statistics epilogue, then the finalize kernel: y and the per-(image,channel)
+// scale/shift the NEXT layer's GroupNorm32(gamma, beta, eps) would apply to y
+int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int W, const float* weight,
+                          const float* bias, int Cout, int ksize, int tile, const float* gamma, const float* beta,
+                          float eps, float* y, float* scale_out, float* shift_out, void* stream) {
+  if (!x || !weight || !y || !gamma || !beta || !scale_out || !shift_out || B < 1) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W;
+  std::vector<void*> tmp;
+  auto dalloc = [&](size_t nfloats, float** p) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(nfloats, 1) * sizeof(float)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  float *a0, *yo, *xp, *st;
+  TRY(dalloc((size_t)B * HW * Cin, &a0));
+  HIPCHK(launch_nchw_to_nhwc(x, a0, B, Cin, HW, s));
+  TRY(dalloc((size_t)B * HW * Cout, &yo));
+  std::vector<float> hw((size_t)Cout * Cin * ksize * ksize);
+  HIPCHK(hipMemcpy(hw.data(), weight, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw) mx = std::max(mx, std::fabs(v));
+  const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx))) : 1.f;
+  TRY(dalloc((f16x3_packed_halfs(Cout, Cin, ksize) + 1) / 2, &xp));
+  HIPCHK(launch_pack_f16x3(weight, xp, Cout, Cin, ksize, wscale, s));
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = a0; g.c0 = Cin; g.lda0 = Cin; g.a0_zo = (long long)HW * Cin;
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.Cin = Cin; g.Cout = Cout;
+  g.ks = ksize; g.stride = 1; g.pad = ksize == 3 ? 1 : 0;
+  g.bias = bias; g.out = yo; g.ldo = Cout; g.o_zo = (long long)HW * Cout; g.ZI = 1; g.Z = B;
+  g.math = MATH_F16X3; g.tile = tile; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
+  g.alpha = 1.0f / (wscale * f16x3_act_scale());
+  const int nblk = gemm_mblocks(g);
+  TRY(dalloc((size_t)B * nblk * Cout * 4, &st));
+  g.stats = reinterpret_cast<double*>(st);
+  hipError_t le = launch_gemm(g, s);
+  GnFin2Args f;
+  memset(&f, 0, sizeof f);
+  f.p0 = g.stats; f.nblk0 = nblk; f.C0 = Cout; f.N = B; f.HW = HW; f.gamma = gamma; f.beta = beta; f.eps = eps;
+  f.scale = scale_out; f.shift = shift_out;
+  if (le == hipSuccess) le = launch_gn_finalize2(f, s);
+  if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, HW, s);
+  hipError_t se = hipStreamSynchronize(s);
+  for (void* p : tmp) (void)hipFree(p);
+  if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv+stats launch: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv+stats sync: ") + hipGetErrorString(se));
+  return 0;
+}
+
+__global__ void fill_hash_kernel(float* p, long long n, unsigned seed, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    p[i] = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;     // uniform [-scale, scale)
+  }
+}
+
+int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                        int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                        void* stream) {
+  if (B < 1 || iters < 1 || !ms_out) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C0 + C1, HW = H * W;
+  int Ho = H, Wo = W;
+  if (upsample) { Ho *= 2; Wo *= 2; }
+  if (stride == 2) { Ho /= 2; Wo /= 2; }
+  std::vector<void*> tmp;
+  auto dalloc = [&](size_t nfloats, float** p, float scale, unsigned seed) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(nfloats, 1) * sizeof(float)));
+    tmp.push_back(*p);
+    hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, *p, (long long)nfloats, seed, scale);
+    return 0;
+  };
+  float *a0, *a1 = nullptr, *w, *wg, *bias, *yo, *rs = nullptr, *sc = nullptr, *sh = nullptr, *ca;
+  TRY(dalloc((size_t)B * HW * C0, &a0, 2.0f, 1));
+  if (C1) TRY(dalloc((size_t)B * HW * C1, &a1, 2.0f, 2));
+  const float wb = 1.0f / std::sqrt((float)Cin * ksize * ksize);
+  TRY(dalloc((size_t)Cout * Cin * ksize * ksize, &w, wb, 3));
+  TRY(dalloc((size_t)Cout * Cin * ksize * ksize, &wg, wb, 3));
+  TRY(dalloc(Cout, &bias, 0.1f, 4));
+  TRY(dalloc((size_t)B * Cout, &ca, 0.5f, 5));
+  TRY(dalloc((size_t)B * Ho * Wo * Cout, &yo, 0.f, 6));
+  if (residual) TRY(dalloc((size_t)B * Ho * Wo * Cout, &rs, 1.0f, 7));
+  if (prologue) {
+    TRY(dalloc((size_t)B * Cin, &sc, 1.0f, 8));
+    TRY(dalloc((size_t)B * Cin, &sh, 0.3f, 9));
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = a0; g.c0 = C0; g.lda0 = C0; g.a0_zo = (long long)HW * C0;
+  if (C1) { g.a1 = a1; g.c1 = C1; g.lda1 = C1; g.a1_zo = (long long)HW * C1; }
+  g.Hin = H; g.Win = W; g.Hout = Ho; g.Wout = Wo; g.Cin = Cin; g.Cout = Cout;
+  g.ks = ksize; g.stride = stride; g.ups = upsample; g.pad = (ksize == 3 && stride == 1) ? 1 : 0;
+  g.pscale = sc; g.pshift = sh; g.silu = prologue ? 1 : 0;
+  g.w = wg; g.ldb = Cout; g.bias = bias;
+  g.chan_add = ca; g.ld_chan_add = Cout;
+  if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
+  g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
+  g.math = MATH_F32; g.tile = tile; g.abl = abl;
+  if (conv_math == ASYRP_MATH_F16X3) {
+    float* xp;
+    TRY(dalloc((f16x3_packed_halfs(Cout, Cin, ksize) + 1) / 2, &xp, 0.f, 10));
+    const float wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(wb)));
+    HIPCHK(launch_pack_f16x3(w, xp, Cout, Cin, ksize, wscale, s));
+    g.math = MATH_F16X3; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
+    g.alpha = 1.0f / (wscale * f16x3_act_scale());
+  }
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  hipError_t le = hipSuccess;
+  for (int i = 0; i < 2 && le == hipSuccess; ++i) le = launch_gemm(g, s);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_gemm(g, s);
+  (void)hipEventRecord(e1, s);
+  hipError_t se = hipStreamSynchronize(s);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (void* p : tmp) (void)hipFree(p);
+  if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench launch: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench sync: ") + hipGetErrorString(se));
+  *ms_out = ms / iters;
   return 0;
 }
 

@@ -31,13 +31,16 @@ struct GemmArgs {
   // 1/(weight scale * f16x3_act_scale())
   int math;                       // MATH_F32 (v_mfma_f32_32x32x2_f32) or MATH_F16X3 (3 x v_mfma_f32_32x32x16_f16)
   const void* wpk; int cout_pad;
+  double* stats;                  // f16x3 only, nullable: per-(image, M-block, out channel) {sum, sumsq} of the output,
+                                  //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
+  int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
 };
 
 enum { MATH_F16X3 = 0, MATH_F32 = 1 };
 
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 
-enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5 };
+enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6 };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -67,6 +70,20 @@ struct GnArgs {
 };
 size_t gn_partial_doubles(int N, int C, int HW);
 hipError_t launch_gn(const GnArgs& a, hipStream_t s);
+int gn_nblk_of(int HW);                       // M-blocks launch_gn_partial writes
+int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats
+// standalone partial statistics of one NHWC tensor -> partial [N][gn_nblk_of(HW)][C][2] doubles
+hipError_t launch_gn_partial(const float* a, int lda, long long a_z, int HW, int N, int C, double* partial, hipStream_t s);
+// GroupNorm(32) scale/shift from per-channel partial statistics of up to two channel-concatenated sources
+struct GnFin2Args {
+  const double* p0; int nblk0; int C0;      // [N][nblk0][C0][2]
+  const double* p1; int nblk1; int C1;      // second source of a concat, or null
+  int N, HW;
+  const float* gamma; const float* beta; float eps;
+  const float* film_scale; const float* film_shift; int ld_film;
+  float* scale; float* shift;               // [N][C0+C1]
+};
+hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s);
 
 hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s);
 

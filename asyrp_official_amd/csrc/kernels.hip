@@ -9,6 +9,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <string.h>
 
 namespace asyrp {
 
@@ -510,6 +511,73 @@ __global__ void gn_finalize_kernel(const GnArgs p, int nblk) {
     p.scale[(size_t)n * p.C + c] = (float)sc;
     p.shift[(size_t)n * p.C + c] = (float)sh;
   }
+}
+
+int gn_nblk_of(int HW) { return gn_nblk(HW); }
+
+hipError_t launch_gn_partial(const float* a, int lda, long long a_z, int HW, int N, int C, double* partial, hipStream_t s) {
+  if ((C & 3) || (lda & 3)) return hipErrorInvalidValue;
+  GnArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = a; g.c0 = C; g.lda0 = lda; g.a0_z = a_z; g.HW = HW; g.N = N; g.C = C; g.partial = partial;
+  const int Q = C / 4;
+  const int PL = Q >= 256 ? 1 : 256 / Q;
+  if (Q * PL > 1024) return hipErrorInvalidValue;
+  const int ppb = gn_ppb(HW), nblk = gn_nblk(HW);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(Q * PL), (size_t)PL * C * 2 * sizeof(double), s, g, ppb, nblk, Q, PL);
+  return hipGetLastError();
+}
+
+// one workgroup per (group, image): fixed-order strided accumulation + fixed-order tree => deterministic
+__global__ void gn_finalize2_kernel(const GnFin2Args p) {
+  __shared__ double sm[256][2];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int C = p.C0 + p.C1, cg = C / 32;
+  double a = 0.0, b = 0.0;
+  // items of this group: (channel j in [0,cg), block k) of the source the channel lives in
+  for (int j = 0; j < cg; ++j) {
+    const int c = g * cg + j;
+    const double* src;
+    int nblk, Cs, cl;
+    if (c < p.C0) { src = p.p0; nblk = p.nblk0; Cs = p.C0; cl = c; }
+    else { src = p.p1; nblk = p.nblk1; Cs = p.C1; cl = c - p.C0; }
+    for (int k = tid; k < nblk; k += 256) {
+      const double* q = src + (((size_t)n * nblk + k) * Cs + cl) * 2;
+      a += q[0];
+      b += q[1];
+    }
+  }
+  sm[tid][0] = a;
+  sm[tid][1] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sm[tid][0] += sm[tid + o][0]; sm[tid][1] += sm[tid + o][1]; }
+    __syncthreads();
+  }
+  const double cnt = (double)cg * p.HW;
+  const double mean = sm[0][0] / cnt;
+  double var = sm[0][1] / cnt - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)p.eps);
+  if (tid < cg) {
+    const int c = g * cg + tid;
+    double sc = (double)p.gamma[c] * rstd;
+    double sh = (double)p.beta[c] - mean * sc;
+    if (p.film_scale) {   // h = GN(h)*(1+scale)+shift  (models/improved_ddpm/unet.py:290-294)
+      const double f = 1.0 + (double)p.film_scale[(size_t)n * p.ld_film + c];
+      sc *= f;
+      sh = sh * f + (double)p.film_shift[(size_t)n * p.ld_film + c];
+    }
+    p.scale[(size_t)n * C + c] = (float)sc;
+    p.shift[(size_t)n * C + c] = (float)sh;
+  }
+}
+
+hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s) {
+  const int C = a.C0 + a.C1;
+  if (C % 32 != 0 || C / 32 > 256 || !a.p0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(32, a.N), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_gn(const GnArgs& a, hipStream_t s) {

@@ -176,6 +176,17 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
                     const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
                     const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,
                     const float* residual, float* y, int conv_math, int tile, void* stream);
+/* f16x3 conv whose epilogue also emits GroupNorm partial statistics of its OUTPUT, followed by the finalize kernel:
+ * y [B,Cout,H,W] and scale/shift [B,Cout] such that y*scale+shift == GroupNorm32(y; gamma, beta, eps) (stride 1). */
+int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int W, const float* weight,
+                          const float* bias, int Cout, int ksize, int tile, const float* gamma, const float* beta,
+                          float eps, float* y, float* scale_out, float* shift_out, void* stream);
+/* Kernel micro-benchmark (scripts/conv_bench.py): times `iters` launches of one conv configuration on synthetic
+ * NHWC buffers with HIP events and returns the average in *ms_out (host pointer).  `abl` != 0 selects the profiling
+ * build of the main f16x3 tile with phases switched off (timing ablations only). */
+int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                        int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                        void* stream);
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
  * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T]. */
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream);

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single conv configurations through the C ABI (asyrp_op_conv_bench): TFLOP/s per tile/variant,
+and timing ablations of the main f16x3 tile.  usage: scripts/conv_bench.py [B]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from asyrp_official_amd import _lib
+
+lib = _lib.load()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+
+
+def run(H, C0, C1, Cout, k, stride=1, ups=0, pro=1, res=0, math="f16x3", tile=0, abl=0, iters=10, b=None):
+    ms = C.c_float()
+    b = b or B
+    _lib.check(lib.asyrp_op_conv_bench(0, b, H, H, C0, C1, Cout, k, stride, ups, pro, res, _lib.CONV_MATH[math], tile, abl,
+                                       iters, C.byref(ms), None))
+    Ho = H * (2 if ups else 1) // stride
+    fl = 2.0 * b * Ho * Ho * Cout * (C0 + C1) * k * k
+    return ms.value, fl / (ms.value * 1e-3) / 1e12
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "one":       # a single configuration, for rocprofv3 --pmc runs
+        for tile in (1, 6):
+            ms, tf = run(256, 128, 0, 128, 3, tile=tile, iters=5)
+            print(f"tile {tile} 128->128 @256 B={B}: {ms:.3f} ms {tf:.1f} TFLOP/s")
+        sys.exit(0)
+    print(f"B={B}")
+    layers = [("down.0 conv 128->128 @256", 256, 128, 0, 128, 3, {}),
+              ("up.0 conv1 256->128 @256 (concat)", 256, 128, 128, 128, 3, {}),
+              ("up.0 nin 1x1 256->128 @256", 256, 128, 128, 128, 1, dict(pro=0)),
+              ("conv2+resid 128->128 @256", 256, 128, 0, 128, 3, dict(res=1)),
+              ("256->256 @64", 64, 256, 0, 256, 3, {}),
+              ("512->256 @64", 64, 256, 256, 256, 3, {}),
+              ("128->128 @128", 128, 128, 0, 128, 3, {}),
+              ("256->256 @32", 32, 256, 0, 256, 3, {}),
+              ("512->512 @16", 16, 512, 0, 512, 3, {}),
+              ("1024->512 @16", 16, 512, 512, 512, 3, {}),
+              ("512->512 @8", 8, 512, 0, 512, 3, {}),
+              ("1024->512 @8", 8, 512, 512, 512, 3, {}),
+              ("upsample 128->128 128->256", 128, 128, 0, 128, 3, dict(ups=1, pro=0)),
+              ("downsample 128->128 256->128", 256, 128, 0, 128, 3, dict(stride=2, pro=0)),
+              ("conv_out 128->3 @256", 256, 128, 0, 3, 3, {}),
+              ("conv_in 3->128 @256", 256, 3, 0, 128, 3, dict(pro=0)),
+              ("qkv 1x1 512->1536 @16", 16, 512, 0, 1536, 1, dict(pro=1)),
+              ]
+    for name, H, C0, C1, Co, k, kw in layers:
+        for math in ("f16x3",):
+            ms, tf = run(H, C0, C1, Co, k, math=math, **kw)
+            print(f"{name:40s} {math:6s} {ms:8.3f} ms {tf:7.1f} TFLOP/s", flush=True)
+    print("-- tile sweep, 128->128 @64 and 512->512 @16 (f16x3)")
+    for (H, Ch) in ((256, 128), (64, 256), (16, 512), (8, 512), (32, 256)):
+        for tile in (1, 2, 3, 4, 6):
+            try:
+                ms, tf = run(H, Ch, 0, Ch, 3, tile=tile)
+                print(f"  {Ch}->{Ch} @{H} tile {tile}: {ms:8.3f} ms {tf:7.1f} TFLOP/s", flush=True)
+            except Exception as e:
+                print("  tile", tile, "failed", e)
+    print("-- ablations of the main tile (128->128 @256, prologue on): abl mask -> ms")
+    for abl in (0, 32, 1 | 32, 2 | 32, 4 | 32, 8 | 32, 16 | 32, 2 | 8 | 32, 1 | 2 | 8 | 32, 4 | 16 | 32, 2 | 8 | 16 | 32):
+        ms, tf = run(256, 128, 0, 128, 3, tile=1, abl=abl)
+        print(f"  abl={abl & 31:2d} (profiling build={bool(abl)}): {ms:8.3f} ms {tf:7.1f} TFLOP/s-equivalent", flush=True)

@@ -110,6 +110,32 @@ def test_f16x3_every_tile_shape(tile, k):
     assert_close(run(), want, what=f"tile {tile} k={k}", **TIGHT)
 
 
+@pytest.mark.parametrize("tile,k,H,W,Cout,offset", [(0, 3, 16, 16, 64, 0.0), (1, 3, 40, 24, 160, 0.0), (2, 1, 40, 24, 96, 0.0),
+                                                    (3, 3, 20, 12, 96, 30.0), (4, 3, 8, 8, 32, 0.0), (6, 3, 32, 32, 128, 5.0)])
+def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
+    """The conv epilogue's per-block {sum, sumsq} partials + finalize == GroupNorm of the conv output (incl. partial
+    tiles, 3-channel groups that are not lane-aligned, and a large mean offset that would break a naive fp32 E[x^2]-m^2)."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    B, Cin = 2, 32
+    x = hash_normal(f"st.x.{tile}", (B, Cin, H, W))
+    w = hash_uniform(f"st.w.{tile}", (Cout, Cin, k, k), -1, 1) / (Cin * k * k) ** 0.5
+    b = 0.1 * hash_uniform(f"st.b.{tile}", (Cout,)) + offset
+    gam, bet = 1 + 0.1 * hash_uniform("st.g", (Cout,)), 0.1 * hash_uniform("st.be", (Cout,))
+    d = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = map(d, (x, w, b, gam, bet))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    sc, sh = torch.empty((B, Cout), device="cuda"), torch.empty((B, Cout), device="cuda")
+    _lib.check(lib.asyrp_op_conv2d_stats(0, _p(xd), Cin, B, H, W, _p(wd), _p(bd), Cout, k, tile, _p(gd), _p(bed), 1e-6,
+                                         _p(y), _p(sc), _p(sh), None))
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x, w, b, padding=k // 2)
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-4, atol=2e-5 * max(1.0, offset))
+    got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
+    assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
+
+
 def test_f16x3_wide_dynamic_range():
     """Operands spanning many binades (weights 1e-4..1, activations 1e-3..1e2): the two-term f16 split with
     power-of-two pre-scaling must stay fp32-equivalent (no f16 subnormal/overflow loss)."""
