@@ -30,8 +30,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int XKC = 16;                 // input channels per K-step (= K of one v_mfma_f32_32x32x16_f16)
-constexpr float ACT_SCALE = 16.0f;      // activations are multiplied by 2^4 before the split (keeps x_lo out of the
-                                        // f16 subnormal range down to |x| ~ 1e-2); folded into alpha on the host
+constexpr float ACT_SCALE = 1.0f;       // optional power-of-two pre-scale of the activations (folded into alpha on the host).
+                                        // 1: x_lo of |x| < 0.125 is an f16 subnormal, i.e. carries an absolute error
+                                        // <= 2^-25 -- the matrix cores keep f16 subnormal inputs (tested), so a UNet's
+                                        // O(1) activations keep fp32-class accuracy without the extra multiply
 constexpr float H_MAX = 65504.0f;
 
 template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_>
@@ -60,14 +62,24 @@ __device__ __forceinline__ float silu_fast(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// two-term f16 split of 8 fp32 values: hi = rn_f16(x), lo = rn_f16(x - hi)  (x - hi is exact in fp32).
+// Pairs go through v_cvt_pk_f16_f32; |x| is clamped to the f16 range first (saturates instead of producing inf).
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float s = __builtin_fminf(__builtin_fmaxf(v[j] * ACT_SCALE, -H_MAX), H_MAX);
-    const _Float16 h = (_Float16)s;
-    const float r = __builtin_fminf(__builtin_fmaxf(s - (float)h, -H_MAX), H_MAX);
-    hi[j] = h;
-    lo[j] = (_Float16)r;
+  for (int j = 0; j < 8; j += 2) {
+    f2 s;
+    s[0] = __builtin_amdgcn_fmed3f(v[j] * ACT_SCALE, -H_MAX, H_MAX);
+    s[1] = __builtin_amdgcn_fmed3f(v[j + 1] * ACT_SCALE, -H_MAX, H_MAX);
+    const h2 h = __builtin_convertvector(s, h2);
+    f2 r;
+    r[0] = s[0] - (float)h[0];
+    r[1] = s[1] - (float)h[1];
+    const h2 l = __builtin_convertvector(r, h2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
   }
 }
 
@@ -76,7 +88,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // ABL: profiling-only instantiation whose phases can be switched off at run time through p.abl (timing ablations;
 //      results are then wrong by construction): 1 = no staging math, 2 = no weight LDS-DMA in the loop, 4 = no MFMA,
 //      8 = no activation loads/writes in the loop, 16 = no per-step wait+barrier.
-template <class T, bool VEC, bool ABL = false>
+// PIPE: software-pipelined K-loop (4-wave tiles): the per-step barrier sits between MFMA pass 2 and pass 3, the next
+//       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
+//       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
+template <class T, bool VEC, bool ABL = false, bool PIPE = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
@@ -200,12 +215,18 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
       if (aoff[i] >= 0 && !(abl & 1)) {
+        // block-uniform prologue mode hoisted out of the element loop (no per-element selects)
+        if (ps) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = t[j];
-          if (ps) v = v * sc[j] + sh[j];
-          if (p.silu) v = silu_fast(v);
-          t[j] = (VEC || c + j < Cin) ? v : 0.f;
+          for (int j = 0; j < 8; ++j) t[j] = __builtin_fmaf(t[j], sc[j], sh[j]);
+        }
+        if (p.silu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = silu_fast(t[j]);
+        }
+        if (!VEC) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = (c + j < Cin) ? t[j] : 0.f;
         }
       }
       h8 hi, lo;
@@ -258,97 +279,168 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const int nchunks = (Cin + XKC - 1) / XKC;
   const int nsteps = nchunks * NTAPS;
 
-  // ---- prologue: stage chunk 0 and the first weight slice ----
-  issue_B(0, 0);
-  gload_A(0);
-  write_A(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int chunk = 0, tap = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const bool more = (step + 1 < nsteps);
-    const bool first_tap = (tap == 0), last_tap = (tap == NTAPS - 1);
-    const bool next_a = (chunk + 1 < nchunks);
-    if (more && !(abl & 2)) issue_B(step + 1, (step + 1) & 1);
-    if (!LOWREG && first_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
-
+  if (PIPE) {
+    // ---- prologue: chunk 0 + weight slice 0 staged, slice 1 in flight, fragments of step 0 in registers ----
+    issue_B(0, 0);
+    gload_A(0);
+    write_A(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nsteps > 1) issue_B(1, 1);
+    if (NTAPS == 1 && nchunks > 1) gload_A(1);   // 1x1: chunk 1 is written during step 0
+    h8 ah[TM], al[TM], bh[TN], bl[TN];
     {
+      const char* A = As + kh * NPIX * 16;
+      const char* B = Bs + boff;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
+    }
+    int chunk = 0, tap = 0;
+    for (int step = 0; step < nsteps; ++step) {
+      const bool last_tap = (tap == NTAPS - 1);
+      const bool next_a = (chunk + 1 < nchunks);
       const int ky = tap / KS, kx = tap - ky * KS;
       const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
       const char* B = Bs + (step & 1) * B_BYTES + boff;
-      // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) is the same in every variant: results are bit-identical across tiles
-      if (LOWREG) {
-        h8 fa[TM], fb[TN];
+      // the step opens with matrix work on register-resident fragments; this step's x_hi / w_lo reads are issued behind
+      // the first MFMA (pinned: the compiler's lgkmcnt wait for al/bh must not sit behind freshly issued reads)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);   // x_lo
+      for (int tm = 0; tm < TM; ++tm) ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);                    // w_hi
+      for (int tn = 0; tn < TN; ++tn) bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn)
+          if (tm + tn > 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);                   // x_hi
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      // next chunk's halo tile (loaded one step ago or earlier) -> LDS, before the barrier that publishes it
+      if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight slice step+1 has landed
+      __syncthreads();                                     // ... and every wave's reads of slice `step` are complete
+      int nchunk = chunk, ntap = tap + 1;
+      if (ntap == NTAPS) { ntap = 0; ++nchunk; }
+      if (step + 2 < nsteps) issue_B(step + 2, step & 1);
+      // activation loads for the chunk after step+1's: issued a full step (3x3: eight steps) before their staging pass
+      if (ntap == (NTAPS > 1 ? 1 : 0) && nchunk + 1 < nchunks) gload_A(nchunk + 1);
+      if (step + 1 < nsteps) {
+        const int nky = ntap / KS, nkx = ntap - nky * KS;
+        const char* An = As + (nchunk & 1) * A_BYTES + (kh * NPIX + nky * TW + nkx) * 16;
+        const char* Bn = Bs + ((step + 1) & 1) * B_BYTES + boff;
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(An + apix[tm] * 16 + 2 * NPIX * 16);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);      // w_lo
+        for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(Bn + tn * 32 * 16);
+      }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
-      } else {
-        h8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
-          al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
-          bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
-        }
-        if (ABL && (abl & 4)) {   // keep the fragment reads alive, drop the matrix work
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(ah[tm]), "v"(al[tm]));
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bh[tn]), "v"(bl[tn]));
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+      tap = ntap;
+      chunk = nchunk;
+    }
+  } else {
+    // ---- prologue: stage chunk 0 and the first weight slice ----
+    issue_B(0, 0);
+    gload_A(0);
+    write_A(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int step = 0; step < nsteps; ++step) {
+      const bool more = (step + 1 < nsteps);
+      const bool first_tap = (tap == 0), last_tap = (tap == NTAPS - 1);
+      const bool next_a = (chunk + 1 < nchunks);
+      if (more && !(abl & 2)) issue_B(step + 1, (step + 1) & 1);
+      if (!LOWREG && first_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
+
+      {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
+        const char* B = Bs + (step & 1) * B_BYTES + boff;
+        // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) is the same in every variant: results are bit-identical across tiles
+        if (LOWREG) {
+          h8 fa[TM], fb[TN];
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);   // x_lo
+  #pragma unroll
+          for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);                    // w_hi
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);                   // x_hi
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+  #pragma unroll
+          for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);      // w_lo
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
         } else {
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          h8 ah[TM], al[TM], bh[TN], bl[TN];
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
+            al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+          }
+  #pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
+            bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
+          }
+          if (ABL && (abl & 4)) {   // keep the fragment reads alive, drop the matrix work
+  #pragma unroll
+            for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(ah[tm]), "v"(al[tm]));
+  #pragma unroll
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(bh[tn]), "v"(bl[tn]));
+          } else {
+  #pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+  #pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+  #pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          }
         }
       }
-    }
 
-    if (last_tap && next_a && !(abl & 8)) {
-      if (LOWREG) gload_A(chunk + 1);
-      write_A(chunk + 1, (chunk + 1) & 1);
+      if (last_tap && next_a && !(abl & 8)) {
+        if (LOWREG) gload_A(chunk + 1);
+        write_A(chunk + 1, (chunk + 1) & 1);
+      }
+      if (!(abl & 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (++tap == NTAPS) { tap = 0; ++chunk; }
     }
-    if (!(abl & 16)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    if (++tap == NTAPS) { tap = 0; ++chunk; }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -466,7 +558,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -478,12 +570,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -518,13 +610,14 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8) ? XT_256x128 : XT_64x128;
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN) ? XT_256x128
+                                                                                                               : XT_64x128;
 }
 
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: bm = 256; break;
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: bm = 256; break;
     case XT_128x128: bm = 128; break;
     default: bm = 64;
   }
@@ -557,26 +650,27 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     return big ? launch_x<X256x128_1, false>(a, s) : launch_x<X64x128_1, false>(a, s);
   }
   if (a.abl) {   // profiling build of the main tile only
-    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3, true, true>(a, s);
     return hipErrorInvalidValue;
   }
   if (a.ks == 3) {
-    if (a.stride == 2) return launch_x<X64x128_3s2, true>(a, s);
+    if (a.stride == 2) return launch_x<X64x128_3s2, true, false, true>(a, s);
     switch (tile) {
-      case XT_256x128: return launch_x<X256x128_3, true>(a, s);
-      case XT_128x128: return launch_x<X128x128_3, true>(a, s);
-      case XT_64x128: return launch_x<X64x128_3, true>(a, s);
-      case XT_64x64: return launch_x<X64x64_3, true>(a, s);
-      case XT_256x64: return launch_x<X256x64_3, true>(a, s);
+      case XT_256x128: return launch_x<X256x128_3, true, false, true>(a, s);
+      case XT_128x128: return launch_x<X128x128_3, true, false, true>(a, s);
+      case XT_64x128: return launch_x<X64x128_3, true, false, true>(a, s);
+      case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
+      case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
+      case XT_256x128_PLAIN: return launch_x<X256x128_3, true>(a, s);
     }
   } else {
     switch (tile) {
-      case XT_256x128: return launch_x<X256x128_1, true>(a, s);
-      case XT_128x128: return launch_x<X128x128_1, true>(a, s);
-      case XT_64x128: return launch_x<X64x128_1, true>(a, s);
-      case XT_64x64: return launch_x<X64x64_1, true>(a, s);
-      case XT_256x64: return launch_x<X256x64_1, true>(a, s);
+      case XT_256x128: return launch_x<X256x128_1, true, false, true>(a, s);
+      case XT_128x128: return launch_x<X128x128_1, true, false, true>(a, s);
+      case XT_64x128: return launch_x<X64x128_1, true, false, true>(a, s);
+      case XT_64x64: return launch_x<X64x64_1, true, false, true>(a, s);
+      case XT_256x64: return launch_x<X256x64_1, true, false, true>(a, s);
     }
   }
   return hipErrorInvalidValue;

@@ -136,6 +136,26 @@ def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-2, 1e-4, 1e-6])
+def test_f16x3_small_magnitude_operands_keep_subnormal_lo_terms(mag):
+    """x = x_hi + x_lo with f16 terms has relative precision 2^-22 while x_lo is a normal f16 (|x| >= 0.125) and an ABSOLUTE
+    precision of 2^-25 below that (x_lo subnormal).  |x| ~ 1e-2 already makes every x_lo subnormal: had the matrix core
+    flushed subnormal inputs, the lo terms would vanish (relative error ~2e-4); instead the error must stay within the
+    representation bound  2^-24 * sum|w|  (+ fp32 accumulation noise)."""
+    B, C, H = 1, 64, 16
+    x = hash_normal(f"sub.x.{mag}", (B, C, H, H)) * mag
+    w = hash_uniform(f"sub.w.{mag}", (C, C, 3, 3), -1, 1) / 24.0
+    b = torch.zeros(C)
+    got = hip_conv(x, w, b, math="f16x3")
+    want = ref_conv(x.double(), w.double(), b.double())
+    err = float((got.double() - want).abs().max())
+    bound = 2.0 ** -24 * float(w.abs().sum(dim=(1, 2, 3)).max()) + 3e-6 * float(want.abs().max())
+    print("mag", mag, "max err", err, "bound", bound, "rel to max|out|", err / float(want.abs().max()))
+    assert err <= bound
+    if mag >= 1e-2:
+        assert err <= 3e-6 * float(want.abs().max())     # fp32-class: subnormal lo terms were not flushed
+
+
 def test_f16x3_wide_dynamic_range():
     """Operands spanning many binades (weights 1e-4..1, activations 1e-3..1e2): the two-term f16 split with
     power-of-two pre-scaling must stay fp32-equivalent (no f16 subnormal/overflow loss)."""
