@@ -91,7 +91,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // PIPE: software-pipelined K-loop (4-wave tiles): the per-step barrier sits between MFMA pass 2 and pass 3, the next
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
-template <class T, bool VEC, bool ABL = false, bool PIPE = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool PRIO = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       const char* B = Bs + (step & 1) * B_BYTES + boff;
       // the step opens with matrix work on register-resident fragments; this step's x_hi / w_lo reads are issued behind
       // the first MFMA (pinned: the compiler's lgkmcnt wait for al/bh must not sit behind freshly issued reads)
+      if (PRIO) __builtin_amdgcn_s_setprio(1);   // the two workgroups of a CU are in different phases: favour the one doing matrix work
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -322,6 +323,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
       // next chunk's halo tile (loaded one step ago or earlier) -> LDS, before the barrier that publishes it
       if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight slice step+1 has landed
@@ -558,7 +560,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool PRIO = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -570,12 +572,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, PRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, PRIO>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -662,7 +664,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128_PLAIN: return launch_x<X256x128_3, true>(a, s);
+      case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, true>(a, s);   // A/B: + s_setprio
     }
   } else {
     switch (tile) {

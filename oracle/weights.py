@@ -138,18 +138,22 @@ def ddpm_param_shapes(cfg, n_delta=1):
 
 
 def synthetic_state_dict(shapes, seed=0):
-    """PyTorch-default-like scales (U(-1/sqrt(fan_in), 1/sqrt(fan_in))); norms near (1, 0)."""
+    """PyTorch-default-like scales (U(-1/sqrt(fan_in), 1/sqrt(fan_in))); norms near (1, 0).
+
+    A parameter pair whose weight is 1-D is a normalisation (GroupNorm gamma/beta); everything else is a
+    conv / linear weight with fan_in = prod(shape[1:]).  No tensor is left at zero, so the reference's
+    zero-initialised modules (improved_ddpm/unet.py:252-254,336,657) are exercised too.
+    """
     sd = OrderedDict()
     for k, shp in shapes.items():
-        leaf = k.rsplit(".", 2)[-2]
-        if "norm" in leaf:
+        wk = k[: -len(".bias")] + ".weight" if k.endswith(".bias") else k
+        wshape = shapes.get(wk, shp)
+        if len(wshape) == 1:
             if k.endswith(".weight"):
                 sd[k] = 1.0 + 0.1 * hash_uniform(k, shp, seed=seed)
             else:
                 sd[k] = 0.1 * hash_uniform(k, shp, seed=seed)
             continue
-        wk = k[: -len(".bias")] + ".weight" if k.endswith(".bias") else k
-        wshape = shapes[wk]
         fan_in = int(np.prod(wshape[1:]))
         bound = 1.0 / fan_in ** 0.5
         sd[k] = hash_uniform(k, shp, -bound, bound, seed=seed)

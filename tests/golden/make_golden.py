@@ -127,6 +127,105 @@ def run_celeba(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def ref_iddpm(cfg, sd, n_delta):
+    """The reference's own UNetModel, built with the arguments create_model passes (improved_ddpm/script_util.py:81-99)."""
+    from models.improved_ddpm.unet import UNetModel
+    m = UNetModel(image_size=cfg.image_size, in_channels=3, model_channels=cfg.num_channels, out_channels=cfg.out_channels,
+                  num_res_blocks=cfg.num_res_blocks, attention_resolutions=tuple(cfg.attention_ds), dropout=0.0,
+                  channel_mult=cfg.channel_mult, num_classes=(1000 if cfg.class_cond else None), use_checkpoint=False,
+                  use_fp16=False, num_heads=4, num_head_channels=cfg.num_head_channels, num_heads_upsample=-1,
+                  use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False)
+    m.setattr_layers(n_delta)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return m.eval()
+
+
+def run_iddpm_small(out):
+    """Small iDDPM UNet (32x32, 32 base channels, 16-channel heads): forwards, learn_sigma steps, a 6+6-step edit."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    torch.set_num_threads(1)
+    cfg = SMALL_I
+    sd = synthetic_state_dict(iddpm_param_shapes(cfg, n_delta=2), seed=11)
+    m = ref_iddpm(cfg, sd, 2)
+    B = 2
+    x = hash_normal("ismall.x", (B, 3, 32, 32), seed=2)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = {}
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", learn_sigma=True)
+    with torch.no_grad():
+        t = torch.ones(B) * 701.0
+        et, _, _, mh = m(x, t)
+        g["fwd_single.et"], g["fwd_single.middle_h"] = et, mh
+        et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
+        et, em, dh, mh = m(x, t, index=1, t_edit=500, hs_coeff=(0.9, 0.7, 0.5))
+        g["fwd_multi.et_mod"], g["fwd_multi.delta_h"] = em, dh
+        et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0), ignore_timestep=True)
+        g["fwd_ignoret.et_mod"], g["fwd_ignoret.delta_h"] = em, dh
+        et, em, dh, mh = m(x, torch.ones(B) * 204.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        assert dh is None and torch.equal(et, em)
+        g["fwd_noedit.et"] = et
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 0.0, t_next=torch.ones(B) * 25.0, eta=0, **kw)
+        g["step_inv.xt_next"], g["step_inv.x0_t"] = xn, x0t
+        xn, x0t, dh, mh = denoising_step(x, t=t, t_next=torch.ones(B) * 675.0, eta=0.0, index=0, t_edit=500,
+                                         hs_coeff=(1.0, 1.0), **kw)
+        g["step_gen.xt_next"], g["step_gen.x0_t"], g["step_gen.delta_h"] = xn, x0t, dh
+        torch.manual_seed(99)
+        z = torch.randn_like(x)
+        torch.manual_seed(99)
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 25.0, t_next=torch.ones(B) * 0.0, eta=1.0, index=0,
+                                       t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        g["step_eta.noise"], g["step_eta.xt_next"], g["step_eta.x0_t"] = z, xn, x0t
+        n_step, t_0, t_edit = 6, 999, 500
+        seq = [int(s + 1e-6) for s in list(np.linspace(0, 1, n_step) * t_0)]
+        seq_next = [-1] + seq[:-1]
+        xx = x.clone()
+        for i, j in zip(seq_next[1:], seq[1:]):
+            xx, _, _, _ = denoising_step(xx, t=torch.ones(B) * i, t_next=torch.ones(B) * j, eta=0, **kw)
+        g["edit.x_T"] = xx.clone()
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            xx, x0t, _, _ = denoising_step(xx, t=torch.ones(B) * i, t_next=torch.ones(B) * j, eta=0.0, index=0,
+                                           t_edit=t_edit, hs_coeff=(1.0, 1.0), **kw)
+        g["edit.x_edit"] = xx
+    g["input.x"] = x
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_afhq(out):
+    """Full-size AFHQ-dog iDDPM (i_DDPM('AFHQ'), 256x256, B=1): single + dual forward, one learn_sigma Asyrp step.
+    Also asserts that guided_Diffusion('MetFACE') (models/guided_diffusion/unet.py) is the same function."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    torch.set_num_threads(os.cpu_count())
+    cfg = AFHQ
+    sd = synthetic_state_dict(iddpm_param_shapes(cfg, n_delta=1), seed=4321)
+    m = ref_iddpm(cfg, sd, 1)
+    x = hash_normal("afhq.x", (1, 3, 256, 256), seed=4321)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = {}
+    with torch.no_grad():
+        t = torch.ones(1) * 768.0
+        et, _, _, mh = m(x, t)
+        g["fwd_single.et"], g["fwd_single.middle_h"] = et, mh
+        et, em, dh, mh = m(x, t, index=0, t_edit=444, hs_coeff=(1.0, 1.0))
+        g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"] = et, em, dh
+        xn, x0t, _, _ = denoising_step(x, t=t, t_next=torch.ones(1) * 743.0, models=m, logvars=np.zeros(1000), b=betas,
+                                       sampling_type="ddim", eta=0.0, learn_sigma=True, index=0, t_edit=444,
+                                       hs_coeff=(1.0, 1.0))
+        g["step_gen.xt_next"], g["step_gen.x0_t"] = xn, x0t
+        from models.guided_diffusion.script_util import guided_Diffusion
+        mg = guided_Diffusion("MetFACE")
+        mg.setattr_layers(1)
+        mg.load_state_dict(sd, strict=True)
+        et_g, em_g, _, _ = mg.eval()(x, t, index=0, t_edit=444, hs_coeff=(1.0, 1.0))
+        assert torch.equal(et_g, et) and torch.equal(em_g, em), "guided_diffusion UNet differs from improved_ddpm UNet"
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -140,10 +239,14 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "afhq"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
+    if a.only in (None, "iddpm_small"):
+        run_iddpm_small(os.path.join(HERE, "iddpm_small.npz"))
+    if a.only in (None, "afhq"):
+        run_afhq(os.path.join(HERE, "iddpm_afhq.npz"))
     if a.only in (None, "small"):
         run_small(os.path.join(HERE, "ddpm_small.npz"))
     if a.only in (None, "celeba"):

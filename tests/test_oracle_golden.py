@@ -108,3 +108,78 @@ def test_full_size_forward_against_reference(golden_celeba):
     assert_close(et, g["fwd_dual.et"], what="et", **loose)
     assert_close(em, g["fwd_dual.et_mod"], what="et_mod", **loose)
     assert_close(dh, g["fwd_dual.delta_h"], what="delta_h", **loose)
+
+
+# ---- iDDPM / ADM family (models/improved_ddpm/unet.py == models/guided_diffusion/unet.py) -------------------------------
+ITIGHT = dict(rtol=1e-5, atol=6e-6)   # functional vs module evaluation order (einsum / pooling) noise
+
+
+def _ismall():
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11)
+    return sd, hash_normal("ismall.x", (2, 3, 32, 32), seed=2), SMALL_I
+
+
+def test_iddpm_forward_variants():
+    from conftest import load_golden
+    from oracle.iddpm import iddpm_forward
+    g = load_golden("iddpm_small.npz")
+    sd, x, cfg = _ismall()
+    assert torch.equal(x, g["input.x"])
+    t = torch.ones(2) * 701.0
+    with torch.no_grad():
+        et, em, dh, mh = iddpm_forward(sd, cfg, x, t)
+        assert em is None and dh is None
+        assert_close(et, g["fwd_single.et"], what="et", **ITIGHT)
+        assert_close(mh, g["fwd_single.middle_h"], what="middle_h", **ITIGHT)
+        et, em, dh, mh = iddpm_forward(sd, cfg, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh), ("fwd_dual.middle_h", mh)):
+            assert_close(got, g[name], what=name, **ITIGHT)
+        _, em, dh, _ = iddpm_forward(sd, cfg, x, t, index=1, t_edit=500, hs_coeff=(0.9, 0.7, 0.5))
+        assert_close(em, g["fwd_multi.et_mod"], what="multi et_mod", **ITIGHT)
+        assert_close(dh, g["fwd_multi.delta_h"], what="multi delta_h", **ITIGHT)
+        _, em, dh, _ = iddpm_forward(sd, cfg, x, t, index=0, t_edit=500, ignore_timestep=True)
+        assert_close(em, g["fwd_ignoret.et_mod"], what="ignoret et_mod", **ITIGHT)
+        assert_close(dh, g["fwd_ignoret.delta_h"], what="ignoret delta_h", **ITIGHT)
+        et, em, dh, _ = iddpm_forward(sd, cfg, x, torch.ones(2) * 204.0, index=0, t_edit=500)
+        assert dh is None and torch.equal(et, em)
+        assert_close(et, g["fwd_noedit.et"], what="noedit et", **ITIGHT)
+
+
+def test_iddpm_learn_sigma_steps_and_edit_loop():
+    from conftest import load_golden
+    from oracle.iddpm import make_model
+    g = load_golden("iddpm_small.npz")
+    sd, x, cfg = _ismall()
+    model = make_model(sd, cfg)
+    b = sampler.beta_schedule()
+    one = torch.ones(2)
+    kw = dict(model=model, b=b, learn_sigma=True)
+    xn, x0t, _, _ = sampler.denoising_step(x, one * 0.0, one * 25.0, eta=0, **kw)
+    assert_close(xn, g["step_inv.xt_next"], what="inv xt_next", **ITIGHT)
+    assert_close(x0t, g["step_inv.x0_t"], what="inv x0_t", **ITIGHT)
+    ek = dict(index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    xn, x0t, dh, _ = sampler.denoising_step(x, one * 701.0, one * 675.0, eta=0.0, **ek, **kw)
+    assert_close(xn, g["step_gen.xt_next"], what="gen xt_next", **ITIGHT)
+    assert_close(dh, g["step_gen.delta_h"], what="gen delta_h", **ITIGHT)
+    xn, x0t, _, _ = sampler.denoising_step(x, one * 25.0, one * 0.0, eta=1.0, noise=g["step_eta.noise"], **ek, **kw)
+    assert_close(xn, g["step_eta.xt_next"], what="eta xt_next", **ITIGHT)
+    x_T = sampler.invert(model, x, b, n_inv=6, learn_sigma=True)
+    assert_close(x_T, g["edit.x_T"], what="x_T", rtol=1e-4, atol=5e-5)
+    x_edit = sampler.generate(model, x_T, b, n_gen=6, t_edit=500, learn_sigma=True)
+    st = (x_edit - g["edit.x_edit"]).abs().max() / g["edit.x_edit"].abs().max()
+    assert float(st) < 1e-4
+
+
+def test_iddpm_full_size_afhq_against_reference():
+    from conftest import load_golden
+    from oracle.iddpm import AFHQ, iddpm_forward, iddpm_param_shapes
+    g = load_golden("iddpm_afhq.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    x = hash_normal("afhq.x", (1, 3, 256, 256), seed=4321)
+    with torch.no_grad():
+        et, em, dh, mh = iddpm_forward(sd, AFHQ, x, torch.ones(1) * 768.0, index=0, t_edit=444, hs_coeff=(1.0, 1.0))
+    assert_close(et, g["fwd_dual.et"], what="et", rtol=1e-4, atol=1e-5)
+    assert_close(em, g["fwd_dual.et_mod"], what="et_mod", rtol=1e-4, atol=1e-5)
+    assert_close(dh, g["fwd_dual.delta_h"], what="delta_h", rtol=1e-4, atol=1e-5)
