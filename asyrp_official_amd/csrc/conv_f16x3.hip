@@ -488,7 +488,13 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
             pixel[q] = (KS == 1) ? (m0 + m) : ((oy0 + m / PW) * p.Wout + ox0 + (m % PW));
           }
           float rv[8];
-          if (rz) {
+          if (rz && p.rups) {   // residual lives at half resolution (nearest x2 of the skip path)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int oy = pixel[q] / p.Wout, ox = pixel[q] - oy * p.Wout;
+              rv[q] = rz[((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) * p.ldr + n];
+            }
+          } else if (rz) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) rv[q] = rz[pixel[q] * p.ldr + n];
           } else {
@@ -528,7 +534,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
             pixel = oy * p.Wout + ox;
           }
           if (ok && nok) {
-            const float v = (acc[tm][tn][r] * p.alpha + add) + (rz ? rz[pixel * p.ldr + n] : 0.f);
+            float rv = 0.f;
+            if (rz) {
+              const int oy = pixel / p.Wout, ox = pixel - oy * p.Wout;
+              rv = p.rups ? rz[((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) * p.ldr + n] : rz[pixel * p.ldr + n];
+            }
+            const float v = (acc[tm][tn][r] * p.alpha + add) + rv;
             outz[pixel * p.ldo + n] = v;
             if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
           }

@@ -120,6 +120,13 @@ struct asyrp_engine {
   float* d_t = nullptr;   // [max_batch] timesteps for the fused step / loops
   Pool pool;
 
+  // iDDPM / ADM family: the module list of UNetModel.__init__ (models/improved_ddpm/unet.py:527-658)
+  struct Layer { int type = 0; /* 0 conv3x3, 1 ResBlock, 2 AttentionBlock */ int cin = 0, cout = 0, mode = 0; /* 1 down, 2 up */
+                 std::string p; };
+  std::vector<std::vector<Layer>> in_blocks, out_blocks;
+  std::vector<Layer> mid_block;
+  int final_ch = 0;
+
   bool prof_on = false;
   std::vector<ProfRec> prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
@@ -228,6 +235,110 @@ void build_specs_ddpm(asyrp_engine* e) {
     sb.lin(p + ".temb_proj", temb, e->bott_ch);
     sb.norm(p + ".norm2", e->bott_ch);
     sb.conv(p + ".conv2", e->bott_ch, e->bott_ch, 1);
+  }
+}
+
+// parameter inventory of the reference UNetModel (models/improved_ddpm/unet.py:469-658 == models/guided_diffusion/unet.py)
+// with resblock_updown=True, use_scale_shift_norm=True (every arch dict of the reference), + DeltaBlocks (:776-853)
+void build_specs_iddpm(asyrp_engine* e) {
+  const asyrp_config& c = e->cfg;
+  auto& v = e->specs;
+  const int mc = c.ch, emb = mc * 4, L = c.n_levels;
+  auto conv = [&](const std::string& p, int cin, int cout, int k) {
+    v.push_back({p + ".weight", {cout, cin, k, k}});
+    v.push_back({p + ".bias", {cout}});
+  };
+  auto conv1d = [&](const std::string& p, int cin, int cout) {
+    v.push_back({p + ".weight", {cout, cin, 1}});
+    v.push_back({p + ".bias", {cout}});
+  };
+  auto norm = [&](const std::string& p, int ch) {
+    v.push_back({p + ".weight", {ch}});
+    v.push_back({p + ".bias", {ch}});
+  };
+  auto lin = [&](const std::string& p, int cin, int cout) {
+    v.push_back({p + ".weight", {cout, cin}});
+    v.push_back({p + ".bias", {cout}});
+  };
+  auto emit = [&](const asyrp_engine::Layer& l) {
+    if (l.type == 0) {
+      conv(l.p, l.cin, l.cout, 3);
+    } else if (l.type == 1) {
+      norm(l.p + ".in_layers.0", l.cin);
+      conv(l.p + ".in_layers.2", l.cin, l.cout, 3);
+      lin(l.p + ".emb_layers.1", emb, 2 * l.cout);
+      norm(l.p + ".out_layers.0", l.cout);
+      conv(l.p + ".out_layers.3", l.cout, l.cout, 3);
+      if (l.cin != l.cout) conv(l.p + ".skip_connection", l.cin, l.cout, 1);
+    } else {
+      norm(l.p + ".norm", l.cin);
+      conv1d(l.p + ".qkv", l.cin, 3 * l.cin);
+      conv1d(l.p + ".proj_out", l.cin, l.cin);
+    }
+  };
+  auto mk = [&](int type, int cin, int cout, int mode, const std::string& p) {
+    asyrp_engine::Layer l;
+    l.type = type; l.cin = cin; l.cout = cout; l.mode = mode; l.p = p;
+    return l;
+  };
+  lin("time_embed.0", mc, emb);
+  lin("time_embed.2", emb, emb);
+  if (c.num_classes > 0) v.push_back({"label_emb.weight", {c.num_classes, emb}});   // built by the reference, never used (:519-520,676-688)
+  int ch = mc * c.ch_mult[0], res = c.resolution;
+  std::vector<int> chans;
+  e->in_blocks.clear(); e->out_blocks.clear(); e->mid_block.clear();
+  e->in_blocks.push_back({mk(0, c.in_channels, ch, 0, "input_blocks.0.0")});
+  chans.push_back(ch);
+  for (int level = 0; level < L; ++level) {
+    for (int j = 0; j < c.num_res_blocks; ++j) {
+      const int n = (int)e->in_blocks.size();
+      std::vector<asyrp_engine::Layer> ls;
+      ls.push_back(mk(1, ch, mc * c.ch_mult[level], 0, S("input_blocks.%d.0", n)));
+      ch = mc * c.ch_mult[level];
+      if (has_attn(c, res)) ls.push_back(mk(2, ch, ch, 0, S("input_blocks.%d.1", n)));
+      e->in_blocks.push_back(ls);
+      chans.push_back(ch);
+    }
+    if (level != L - 1) {
+      const int n = (int)e->in_blocks.size();
+      e->in_blocks.push_back({mk(1, ch, ch, 1, S("input_blocks.%d.0", n))});
+      chans.push_back(ch);
+      res /= 2;
+    }
+  }
+  e->mid_block = {mk(1, ch, ch, 0, "middle_block.0"), mk(2, ch, ch, 0, "middle_block.1"), mk(1, ch, ch, 0, "middle_block.2")};
+  e->bott_ch = ch;
+  e->bott_res = res;
+  e->temb_ch = emb;
+  for (int level = L - 1; level >= 0; --level) {
+    for (int i = 0; i < c.num_res_blocks + 1; ++i) {
+      const int ich = chans.back();
+      chans.pop_back();
+      const int n = (int)e->out_blocks.size();
+      std::vector<asyrp_engine::Layer> ls;
+      ls.push_back(mk(1, ch + ich, mc * c.ch_mult[level], 0, S("output_blocks.%d.0", n)));
+      ch = mc * c.ch_mult[level];
+      if (has_attn(c, res)) ls.push_back(mk(2, ch, ch, 0, S("output_blocks.%d.%d", n, (int)ls.size())));
+      if (level && i == c.num_res_blocks) {
+        ls.push_back(mk(1, ch, ch, 2, S("output_blocks.%d.%d", n, (int)ls.size())));
+        res *= 2;
+      }
+      e->out_blocks.push_back(ls);
+    }
+  }
+  e->final_ch = ch;
+  for (auto& b : e->in_blocks) for (auto& l : b) emit(l);
+  for (auto& l : e->mid_block) emit(l);
+  for (auto& b : e->out_blocks) for (auto& l : b) emit(l);
+  norm("out.0", ch);
+  conv("out.2", ch, c.out_channels, 3);
+  for (int d = 0; d < c.n_delta; ++d) {
+    const std::string p = S("layer_%d", d);
+    norm(p + ".in_layers.0", e->bott_ch);
+    conv(p + ".in_layers.2", e->bott_ch, e->bott_ch, 1);
+    lin(p + ".emb_layers.1", emb, e->bott_ch);
+    norm(p + ".out_layers.0", e->bott_ch);
+    conv(p + ".out_layers.3", e->bott_ch, e->bott_ch, 1);
   }
 }
 
@@ -350,7 +461,7 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
-         const Act* resid, Act* out, bool want_stats = false) {
+         const Act* resid, Act* out, bool want_stats = false, int rups = 0) {
   const int Hin = x0.H, Win = x0.W;
   int Ho = Hin, Wo = Win;
   if (ups) { Ho *= 2; Wo *= 2; }
@@ -371,7 +482,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.ldb = Cout;
   g.bias = bname.empty() ? nullptr : P(c, bname);
   g.chan_add = chan_add; g.ld_chan_add = c.e->tproj_total;
-  if (resid) { g.resid = resid->p; g.ldr = resid->C; g.r_zo = resid->per_image(); }
+  if (resid) { g.resid = resid->p; g.ldr = resid->C; g.r_zo = resid->per_image(); g.rups = rups; }
   g.alpha = 1.0f;
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
   g.ZI = 1; g.Z = c.B;
@@ -397,7 +508,8 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
 // GroupNorm(32, eps) of the virtual concat (x0|x1) -> scale/shift [B][C] (pool buffers returned to the caller).
 // Per-channel partial statistics come from the producing conv's epilogue when it wrote them (Act::st); a tensor without
 // them (h-space mix output, fp32-MFMA mode) gets one standalone reduction pass.
-int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float eps, float** scale, float** shift) {
+int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float eps, float** scale, float** shift,
+       const float* film_scale = nullptr, const float* film_shift = nullptr, int ld_film = 0) {
   const int C = x0.C + (x1 ? x1->C : 0);
   const int HW = x0.H * x0.W;
   TRY(c.e->pool.get((size_t)c.B * C, scale));
@@ -425,6 +537,7 @@ int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float ep
   a.beta = P(c, prefix + ".bias");
   if (!a.gamma || !a.beta) return fail(ASYRP_EKEY, "missing norm params " + prefix);
   a.eps = eps;
+  a.film_scale = film_scale; a.film_shift = film_shift; a.ld_film = ld_film;
   a.scale = *scale; a.shift = *shift;
   HIPCHK(launch_gn_finalize2(a, c.s));
   for (int k = 0; k < 2; ++k)
@@ -565,8 +678,212 @@ int decoder(Ctx& c, const Act& hin, const std::vector<Act>& skips, Act* eps) {
 
 // DDPM.forward (models/ddpm/diffusion.py:473-580) on NHWC buffers.  Outputs are pool buffers (NHWC) the
 // caller drops.  et_mod.p == nullptr when no second decoder ran (index<0, or index>=0 without edit: ε̃ ≡ ε).
+// ---------------------------------------------------------------------------------------------------
+// iDDPM / ADM family (models/improved_ddpm/unet.py; models/guided_diffusion/unet.py is the same network)
+// ---------------------------------------------------------------------------------------------------
+constexpr float EPS_I = 1e-5f;   // GroupNorm32 default eps (improved_ddpm/nn.py:17-19, 100)
+
+// ResBlock._forward (:278-298), use_scale_shift_norm=True: GN-SiLU-[up|down]-conv3x3, FiLM(GN(h))-SiLU-conv3x3, + skip(x)
+int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x1, Act* out) {
+  asyrp_engine* e = c.e;
+  const std::string& p = L.p;
+  const int Cin = x0.C + (x1 ? x1->C : 0), Cout = L.cout;
+  if (Cin != L.cin) return fail(ASYRP_EINVAL, "channel mismatch entering " + p);
+  float *sc1, *sh1, *sc2, *sh2;
+  TRY(gn(c, x0, x1, p + ".in_layers.0", EPS_I, &sc1, &sh1));
+  Act h1, xr;          // xr: the (pooled) input of the skip path when the block resamples
+  bool own_xr = false;
+  int rups = 0;
+  const Act* skip_src = &x0;
+  if (L.mode == 1) {   // down: 2x2 average of the ACTIVATED tensor and of x (:279-284, Downsample with use_conv=False)
+    if (x1) return fail(ASYRP_EINVAL, "down-sampling ResBlock takes a single input");
+    Act hp;
+    TRY(new_act(c, x0.C, x0.H / 2, x0.W / 2, &hp));
+    TRY(new_act(c, x0.C, x0.H / 2, x0.W / 2, &xr));
+    own_xr = true;
+    HIPCHK(launch_pool2(x0.p, c.B, x0.H, x0.W, x0.C, sc1, sh1, hp.p, xr.p, c.s));
+    TRY(conv(c, hp, nullptr, p + ".in_layers.2.weight", p + ".in_layers.2.bias", Cout, 3, 1, 0, nullptr, nullptr, 0, nullptr,
+             nullptr, &h1, true));
+    drop(c, hp);
+    skip_src = &xr;
+  } else if (L.mode == 2) {   // up: nearest x2 of the activated tensor (folded into the conv's gather) and of x (epilogue)
+    if (x1) return fail(ASYRP_EINVAL, "up-sampling ResBlock takes a single input");
+    TRY(conv(c, x0, nullptr, p + ".in_layers.2.weight", p + ".in_layers.2.bias", Cout, 3, 1, 1, sc1, sh1, 1, nullptr, nullptr,
+             &h1, true));
+    rups = 1;
+  } else {
+    TRY(conv(c, x0, x1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", Cout, 3, 1, 0, sc1, sh1, 1, nullptr, nullptr, &h1,
+             true));
+  }
+  e->pool.put(sc1); e->pool.put(sh1);
+  // h = GN(h) * (1 + scale) + shift, (scale, shift) = chunk(Linear(SiLU(emb)), 2)  (:290-294)
+  const float* film = c.tproj + e->tproj_off.at(p);
+  TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, e->tproj_total));
+  Act sk;
+  bool own_sk = false;
+  if (Cin != Cout) {   // 1x1 skip_connection (never combined with up/down in the reference's arch dicts)
+    if (L.mode) return fail(ASYRP_EINVAL, "resampling ResBlock with a channel change is not part of any reference config");
+    TRY(conv(c, x0, x1, p + ".skip_connection.weight", p + ".skip_connection.bias", Cout, 1, 1, 0, nullptr, nullptr, 0, nullptr,
+             nullptr, &sk));
+    own_sk = true;
+    skip_src = &sk;
+  }
+  TRY(conv(c, h1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, skip_src,
+           out, true, rups));
+  e->pool.put(sc2); e->pool.put(sh2);
+  drop(c, h1);
+  if (own_sk) drop(c, sk);
+  if (own_xr) drop(c, xr);
+  return 0;
+}
+
+// AttentionBlock + QKVAttentionLegacy (:341-347, 379-396): GN -> Conv1d(C,3C) -> per head [q|k|v] -> softmax(q.k/sqrt(ch)) v
+// -> Conv1d(C,C) -> + x
+int attnblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x, Act* out) {
+  const std::string& p = L.p;
+  float *sc, *sh;
+  TRY(gn(c, x, nullptr, p + ".norm", EPS_I, &sc, &sh));
+  Act qkv;
+  TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  const int nhc = c.e->cfg.num_head_channels;
+  if (nhc <= 0 || x.C % nhc) return fail(ASYRP_EINVAL, "num_head_channels must divide the attention width");
+  const int heads = x.C / nhc;
+  Act o;
+  TRY(new_act(c, x.C, x.H, x.W, &o));
+  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, heads, 1.0f / std::sqrt((float)nhc), o.p));
+  drop(c, qkv);
+  TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr, &x, out,
+           true));
+  drop(c, o);
+  return 0;
+}
+
+// DeltaBlock.forward (:835-853; use_scale_shift_norm=False): GN-SiLU-conv1x1, (+Linear(SiLU(emb))), GN-SiLU-conv1x1
+int deltablock_i(Ctx& c, const std::string& p, const Act& h, bool use_emb, Act* out) {
+  float *sc, *sh;
+  TRY(gn(c, h, nullptr, p + ".in_layers.0", EPS_I, &sc, &sh));
+  Act d1;
+  TRY(conv(c, h, nullptr, p + ".in_layers.2.weight", p + ".in_layers.2.bias", h.C, 1, 1, 0, sc, sh, 1,
+           use_emb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1, true));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  TRY(gn(c, d1, nullptr, p + ".out_layers.0", EPS_I, &sc, &sh));
+  TRY(conv(c, d1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", h.C, 1, 1, 0, sc, sh, 1, nullptr, nullptr, out));
+  c.e->pool.put(sc); c.e->pool.put(sh);
+  drop(c, d1);
+  return 0;
+}
+
+// one TimestepEmbedSequential: layers applied in order; the first may read the virtual concat (x0|x1)
+int run_layers_i(Ctx& c, const std::vector<asyrp_engine::Layer>& ls, const Act& x0, const Act* x1, Act* out) {
+  Act h = x0;
+  bool own = false;
+  for (size_t k = 0; k < ls.size(); ++k) {
+    const asyrp_engine::Layer& L = ls[k];
+    const Act* second = (k == 0) ? x1 : nullptr;
+    Act o;
+    if (L.type == 0) {
+      TRY(conv(c, h, second, L.p + ".weight", L.p + ".bias", L.cout, 3, 1, 0, nullptr, nullptr, 0, nullptr, nullptr, &o, true));
+    } else if (L.type == 1) {
+      TRY(resblock_i(c, L, h, second, &o));
+    } else {
+      TRY(attnblock_i(c, L, h, &o));
+    }
+    if (own) drop(c, h);
+    h = o;
+    own = true;
+  }
+  *out = h;
+  return 0;
+}
+
+int decoder_i(Ctx& c, const Act& hin, const std::vector<Act>& hs, Act* eps) {
+  asyrp_engine* e = c.e;
+  int k = (int)hs.size() - 1;
+  Act h = hin;
+  bool own = false;
+  for (auto& blk : e->out_blocks) {
+    Act o;
+    TRY(run_layers_i(c, blk, h, &hs[k], &o));
+    --k;
+    if (own) drop(c, h);
+    h = o;
+    own = true;
+  }
+  float *sc, *sh;
+  TRY(gn(c, h, nullptr, "out.0", EPS_I, &sc, &sh));
+  TRY(conv(c, h, nullptr, "out.2.weight", "out.2.bias", e->cfg.out_channels, 3, 1, 0, sc, sh, 1, nullptr, nullptr, eps));
+  e->pool.put(sc); e->pool.put(sh);
+  if (own) drop(c, h);
+  return 0;
+}
+
+// UNetModel.forward (models/improved_ddpm/unet.py:676-752) on NHWC buffers; same output contract as unet_core_ddpm
+int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int apply_edit, const float* coeff,
+                    int ignore_t, Act* et, Act* et_mod, Act* last_delta, Act* middle) {
+  asyrp_engine* e = c.e;
+  const asyrp_config& cf = e->cfg;
+  et_mod->p = nullptr;
+  last_delta->p = nullptr;
+  float *temb, *temb_act;
+  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
+  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
+  TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
+  // timestep_embedding [cos|sin] (nn.py:103-121) -> time_embed = Linear, SiLU, Linear (:513-517); every block's
+  // emb_layers = Linear(SiLU(emb)) in one launch
+  HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 0, P(c, "time_embed.0.weight"), P(c, "time_embed.0.bias"),
+                         P(c, "time_embed.2.weight"), P(c, "time_embed.2.bias"), cf.ch, e->temb_ch, temb, temb_act, c.B,
+                         c.s));
+  HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
+                            e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  e->pool.put(temb);
+  e->pool.put(temb_act);
+  std::vector<Act> hs;
+  Act xin;
+  xin.p = const_cast<float*>(x_nhwc); xin.C = cf.in_channels; xin.H = cf.resolution; xin.W = cf.resolution;
+  for (size_t n = 0; n < e->in_blocks.size(); ++n) {
+    Act o;
+    TRY(run_layers_i(c, e->in_blocks[n], n == 0 ? xin : hs.back(), nullptr, &o));
+    hs.push_back(o);
+  }
+  Act h;
+  TRY(run_layers_i(c, e->mid_block, hs.back(), nullptr, &h));
+  *middle = h;
+  if (index >= 0 && apply_edit) {   // :697-704
+    std::vector<Act> deltas(index + 1);
+    const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
+    for (int i = 0; i <= index; ++i) {
+      TRY(deltablock_i(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
+      dptr[i] = deltas[i].p;
+    }
+    Act h2;
+    TRY(new_act(c, h.C, h.H, h.W, &h2));
+    HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
+    for (int i = 0; i < index; ++i) drop(c, deltas[i]);
+    *last_delta = deltas[index];
+    TRY(decoder_i(c, h2, hs, et_mod));
+    drop(c, h2);
+  }
+  TRY(decoder_i(c, h, hs, et));
+  for (auto& a : hs) drop(c, a);
+  e->pool.put(c.tproj);
+  c.tproj = nullptr;
+  return 0;
+}
+
+int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int apply_edit, const float* coeff,
+                   int ignore_t, Act* et, Act* et_mod, Act* last_delta, Act* middle);
+
 int unet_core(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int apply_edit, const float* coeff,
               int ignore_t, Act* et, Act* et_mod, Act* last_delta, Act* middle) {
+  if (c.e->cfg.family == ASYRP_FAMILY_IDDPM)
+    return unet_core_iddpm(c, x_nhwc, t_dev, index, apply_edit, coeff, ignore_t, et, et_mod, last_delta, middle);
+  return unet_core_ddpm(c, x_nhwc, t_dev, index, apply_edit, coeff, ignore_t, et, et_mod, last_delta, middle);
+}
+
+int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, int apply_edit, const float* coeff,
+                   int ignore_t, Act* et, Act* et_mod, Act* last_delta, Act* middle) {
   asyrp_engine* e = c.e;
   const asyrp_config& cf = e->cfg;
   const int L = cf.n_levels, R = cf.resolution;
@@ -695,7 +1012,9 @@ const char* asyrp_last_error(void) { return g_err.c_str(); }
 
 int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int device) {
   if (!out || !cfg) return fail(ASYRP_EINVAL, "null argument");
-  if (cfg->family != ASYRP_FAMILY_DDPM) return fail(ASYRP_EINVAL, "only the DDPM family is implemented in this build");
+  if (cfg->family != ASYRP_FAMILY_DDPM && cfg->family != ASYRP_FAMILY_IDDPM) return fail(ASYRP_EINVAL, "unknown UNet family");
+  if (cfg->family == ASYRP_FAMILY_IDDPM && (cfg->num_head_channels <= 0 || cfg->num_classes < 0))
+    return fail(ASYRP_EINVAL, "iDDPM family needs num_head_channels > 0");
   if (cfg->n_levels < 1 || cfg->n_levels > ASYRP_MAX_LEVELS || cfg->ch % 32 != 0 || max_batch < 1 || cfg->n_delta < 0 ||
       cfg->n_delta > 4 || cfg->resolution % (1 << (cfg->n_levels - 1)) != 0)
     return fail(ASYRP_EINVAL, "unsupported configuration");
@@ -706,7 +1025,8 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   e->math = (cfg->conv_math == ASYRP_MATH_F32) ? MATH_F32 : MATH_F16X3;
   e->max_batch = max_batch;
   e->device = device;
-  build_specs_ddpm(e);
+  if (cfg->family == ASYRP_FAMILY_IDDPM) build_specs_iddpm(e);
+  else build_specs_ddpm(e);
   for (size_t i = 0; i < e->specs.size(); ++i) e->spec_idx[e->specs[i].key] = (int)i;
   e->host.resize(e->specs.size());
   e->loaded.assign(e->specs.size(), 0);
@@ -782,11 +1102,14 @@ int asyrp_finalize_params(asyrp_engine* e) {
   std::vector<float> tw, tb;
   e->tproj_off.clear();
   int off = 0;
+  // per-block timestep projections: DDPM `<block>.temb_proj`, iDDPM `<block>.emb_layers.1`
+  const char* tsuf = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".emb_layers.1" : ".temb_proj";
+  const std::string tw_suf = std::string(tsuf) + ".weight", tb_suf = std::string(tsuf) + ".bias";
   for (auto& s : e->specs) {
-    if (!ends_with(s.key, ".temb_proj.weight")) continue;
-    const std::string p = s.key.substr(0, s.key.size() - strlen(".temb_proj.weight"));
+    if (!ends_with(s.key, tw_suf)) continue;
+    const std::string p = s.key.substr(0, s.key.size() - tw_suf.size());
     const auto& w = hostp(e, s.key);
-    const auto& b = hostp(e, p + ".temb_proj.bias");
+    const auto& b = hostp(e, p + tb_suf);
     e->tproj_off[p] = off;
     tw.insert(tw.end(), w.begin(), w.end());
     tb.insert(tb.end(), b.begin(), b.end());
@@ -797,9 +1120,10 @@ int asyrp_finalize_params(asyrp_engine* e) {
   TRY(upload(e, "__tproj.bias", tb));
   for (auto& s : e->specs) {
     const auto& v = hostp(e, s.key);
-    if (ends_with(s.key, ".temb_proj.weight") || ends_with(s.key, ".temb_proj.bias")) continue;
-    if (s.shape.size() == 4) {
-      const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (int)s.shape[2];
+    if (ends_with(s.key, tw_suf) || ends_with(s.key, tb_suf)) continue;
+    if (s.key == "label_emb.weight") continue;   // never read by forward (models/improved_ddpm/unet.py:676-688)
+    if (s.shape.size() == 4 || s.shape.size() == 3) {   // Conv2d, or Conv1d with kernel 1 (attention qkv / proj_out)
+      const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (s.shape.size() == 4) ? (int)s.shape[2] : 1;
       const std::string p = s.key.substr(0, s.key.size() - strlen(".weight"));
       if (ends_with(p, ".q")) {   // fuse q|k|v into one [Cin][3C] operand
         const std::string ap = p.substr(0, p.size() - 2);

@@ -23,6 +23,8 @@ struct GemmArgs {
   const float* bias;              // [Cout] or null
   const float* chan_add; int ld_chan_add;   // [zo][ld] or null
   const float* resid; int ldr; long long r_zo, r_zi;
+  int rups;                       // residual is at half resolution: read pixel (oy>>1, ox>>1) of a (Hout/2 x Wout/2) tensor
+                                  //   (nearest x2 of the skip path inside an iDDPM ResBlock(up=True), improved_ddpm/unet.py:281-283)
   float alpha;
   float* out; int ldo; long long o_zo, o_zi;
   int ZI, Z;
@@ -99,6 +101,11 @@ hipError_t launch_linear_rows(const float* x, int ldx, const float* W, const flo
 // h2 = c0*h + sum_i c_{i+1} * d_i      (n_d <= 4), elementwise over `n` floats
 hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2,
                       long long n, hipStream_t s);
+
+// iDDPM ResBlock(down=True) (models/improved_ddpm/unet.py:279-284): hp = avgpool2(silu(x*scale+shift)), xp = avgpool2(x),
+// NHWC, H and W even; scale/shift [N][C] are the GroupNorm apply terms of in_layers.0
+hipError_t launch_pool2(const float* x, int N, int H, int W, int C, const float* scale, const float* shift, float* hp,
+                        float* xp, hipStream_t s);
 
 // NCHW <-> NHWC
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, hipStream_t s);

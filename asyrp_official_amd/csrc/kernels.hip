@@ -311,7 +311,12 @@ __global__ void __launch_bounds__(T::NT) igemm_f32_kernel(const GemmArgs p) {
           float v = acc[tm][tn][r] * p.alpha;
           if (has_b) v = v + bn;
           if (has_c) v = v + cn;
-          if (rz) v = v + rz[pixel * p.ldr + n];
+          if (rz) {
+            long long rp = pixel;
+            if (p.rups) rp = (KS == 1) ? (long long)((pixel / p.Wout) >> 1) * (p.Wout >> 1) + ((pixel % p.Wout) >> 1)
+                                       : (long long)((oy0 + m / PW) >> 1) * (p.Wout >> 1) + ((ox0 + (m % PW)) >> 1);
+            v = v + rz[rp * p.ldr + n];
+          }
           outz[pixel * p.ldo + n] = v;
         }
       }
@@ -720,6 +725,52 @@ hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_
   for (int k = 0; k < 5; ++k) a.c[k] = (k <= n_d) ? coeff_host[k] : 0.f;
   const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipLaunchKernelGGL(mix_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// 2x2 average pooling of the activated tensor and of the raw tensor (iDDPM down-sampling ResBlock)
+// =====================================================================================================
+__global__ void pool2_kernel(const float* x, int H, int W, int C, const float* scale, const float* shift, float* hp,
+                             float* xp, long long total4) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long r = i / C4;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)n * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)n * C + c);
+    float ha[4] = {0, 0, 0, 0}, xa[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xa[j] += vv[j];
+          ha[j] += silu_f(vv[j] * ss[j] + hh[j]);
+        }
+      }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+    *reinterpret_cast<float4*>(hp + o) = make_float4(ha[0] * 0.25f, ha[1] * 0.25f, ha[2] * 0.25f, ha[3] * 0.25f);
+    *reinterpret_cast<float4*>(xp + o) = make_float4(xa[0] * 0.25f, xa[1] * 0.25f, xa[2] * 0.25f, xa[3] * 0.25f);
+  }
+}
+
+hipError_t launch_pool2(const float* x, int N, int H, int W, int C, const float* scale, const float* shift, float* hp,
+                        float* xp, hipStream_t s) {
+  if ((C & 3) || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+  const long long total4 = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  long long b = (total4 + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)b), dim3(256), 0, s, x, H, W, C, scale, shift, hp, xp, total4);
   return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@ denoising_step :24-104) on top of the HIP engine's fused DDIM step (asyrp_ddim_s
 import numpy as np
 import torch
 
-from .ddpm import DDPM
+from ._base import HipUNet
 
 
 def get_beta_schedule(*, beta_start, beta_end, num_diffusion_timesteps):
@@ -22,7 +22,7 @@ def extract(a, t, x_shape):
 
 def _unwrap(models):
     m = models.module if isinstance(models, torch.nn.DataParallel) else models
-    if not isinstance(m, DDPM):
+    if not isinstance(m, HipUNet):
         raise TypeError(f"denoising_step expects an asyrp_official_amd UNet, got {type(m).__name__}")
     return m
 

@@ -9,7 +9,7 @@ from . import _lib
 
 
 def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channels, ch, ch_mult, num_res_blocks,
-                attn_resolutions, num_head_channels=0, n_delta=0, conv_math="f16x3"):
+                attn_resolutions, num_head_channels=0, n_delta=0, conv_math="f16x3", num_classes=0):
     cfg = _lib.AsyrpConfig()
     cfg.family, cfg.resolution, cfg.in_channels, cfg.out_channels = family, resolution, in_channels, out_channels
     cfg.ch, cfg.n_levels, cfg.num_res_blocks = ch, len(ch_mult), num_res_blocks
@@ -20,6 +20,7 @@ def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channel
         cfg.attn_resolutions[i] = int(r)
     cfg.num_head_channels, cfg.n_delta = num_head_channels, n_delta
     cfg.conv_math = _lib.CONV_MATH[conv_math] if isinstance(conv_math, str) else int(conv_math)
+    cfg.num_classes = int(num_classes)
     return cfg
 
 
@@ -72,7 +73,7 @@ class Engine:
         self.h = C.c_void_p()
         _lib.check(self.lib.asyrp_create(C.byref(self.h), C.byref(cfg), self.max_batch, self.device_index))
         self.out_channels, self.resolution = cfg.out_channels, cfg.resolution
-        self.bott_ch = cfg.ch * cfg.ch_mult[cfg.n_levels - 1]
+        self.bott_ch = cfg.ch * cfg.ch_mult[cfg.n_levels - 1]      # both families end the encoder at ch * ch_mult[-1]
         self.bott_res = cfg.resolution >> (cfg.n_levels - 1)
 
     def close(self):

@@ -43,7 +43,8 @@ extern "C" {
 /* UNet families of the reference (diffusion_latent.py:76-126 picks one by dataset). */
 enum asyrp_family {
   ASYRP_FAMILY_DDPM = 0, /* models/ddpm/diffusion.py:327 DDPM(config)      — CelebA-HQ, LSUN */
-  ASYRP_FAMILY_IDDPM = 1 /* models/improved_ddpm/unet.py:437 UNetModel     — AFHQ, ImageNet, MetFaces */
+  ASYRP_FAMILY_IDDPM = 1 /* models/improved_ddpm/unet.py:437 UNetModel (= models/guided_diffusion/unet.py:437) — AFHQ, FFHQ,
+                            ImageNet, MetFaces, CelebA-HQ-P2; resblock_updown + scale-shift norm as in every arch dict */
 };
 
 /* Arithmetic of the implicit-GEMM convolutions.  Both are fp32-equivalent (same error class vs the reference's
@@ -68,7 +69,8 @@ typedef struct asyrp_config {
   int32_t num_head_channels;      /* iDDPM: 64; DDPM: 0 = single head over all channels */
   int32_t n_delta;                /* number of DeltaBlocks layer_0..layer_{n-1} (setattr_layers) */
   int32_t conv_math;              /* enum asyrp_conv_math: how the conv / 1x1 GEMMs are evaluated */
-  int32_t reserved[7];
+  int32_t num_classes;            /* iDDPM class_cond: 1000 adds the (unused) label_emb.weight key; else 0 */
+  int32_t reserved[6];
 } asyrp_config;
 
 typedef struct asyrp_engine asyrp_engine;

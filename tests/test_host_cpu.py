@@ -130,3 +130,34 @@ def test_two_rank_gloo_shard_and_all_gather(tmp_path, n_total):
     full = torch.arange(n_total * 3 * 4 * 4, dtype=torch.float32).reshape(n_total, 3, 4, 4) * 2.0 + 1.0
     for r in range(2):
         assert torch.equal(torch.load(os.path.join(tmp_path, f"r{r}.pt")), full)
+
+
+def test_iddpm_parameter_inventory_and_factories():
+    """i_DDPM / guided_Diffusion mirrors expose exactly the reference UNetModel state_dict (pinned via make_golden's strict load)."""
+    from asyrp_official_amd import guided_Diffusion, i_DDPM
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    want = {k: tuple(v) for k, v in iddpm_param_shapes(AFHQ, n_delta=1).items()}
+    for m in (i_DDPM("AFHQ"), i_DDPM("FFHQ"), guided_Diffusion("MetFACE"), guided_Diffusion("CelebA_HQ_P2")):
+        m.setattr_layers(1)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    fx = json.load(open(os.path.join(GOLDEN, "delta_checkpoint_keys.json")))
+    assert {k: list(v.shape) for k, v in m.layer_0.state_dict().items()} == fx["dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"]
+    with pytest.raises(NotImplementedError):
+        from asyrp_official_amd import UNetModel
+        UNetModel(64, 3, 32, 3, 1, (2,), channel_mult=(1, 2), num_head_channels=16)     # no updown / scale-shift: unused by the reference
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "checkpoint")), reason="reference checkpoints not on this box")
+def test_shipped_iddpm_delta_checkpoints_load_unmodified():
+    from asyrp_official_amd import i_DDPM
+    m = i_DDPM("AFHQ", max_batch=1)
+    m.setattr_layers(1)
+    n = 0
+    for f in sorted(os.listdir(os.path.join(REF, "checkpoint"))):
+        sd = torch.load(os.path.join(REF, "checkpoint", f), map_location="cpu", weights_only=False)["0"]
+        if "in_layers.2.weight" not in sd:
+            continue
+        res = m.layer_0.load_state_dict(sd)
+        assert not res.missing_keys and not res.unexpected_keys
+        n += 1
+    assert n >= 5
