@@ -43,7 +43,7 @@ def celeba_namespace():
                      data=Namespace(image_size=c["resolution"]))
 
 
-def cpu_baseline(model_cpu_sd, betas):
+def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False):
     """Oracle (CPU restatement of the reference, kind="port") timed on this host's cores on a bounded sample:
     B=1, 2 inversion steps + 2 Asyrp steps (dual decoder, as the reference executes them), extrapolated
     linearly to the 39 + 40 steps of one edit."""
@@ -52,20 +52,25 @@ def cpu_baseline(model_cpu_sd, betas):
     # physical cores visible to this process (torch's default intra-op pool); os.cpu_count() counts SMT siblings
     cores = max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0))))
     torch.set_num_threads(cores)
-    cfg = DDPMConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in CELEBA.items()})
-    model = osamp.make_model(model_cpu_sd, cfg)
+    if family == "ddpm":
+        cfg = DDPMConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in CELEBA.items()})
+        model = osamp.make_model(model_cpu_sd, cfg)
+    else:
+        from oracle import iddpm as oi
+        model = oi.make_model(model_cpu_sd, oi.AFHQ if family == "afhq" else oi.IMAGENET)
     g = torch.Generator().manual_seed(1234)
     x = 2 * torch.rand((1, 3, 256, 256), generator=g) - 1
     one = torch.ones(1)
-    osamp.denoising_step(x, one * 0.0, one * 25.0, model=model, b=betas, eta=0)          # warm-up
+    ls = dict(learn_sigma=learn_sigma)
+    osamp.denoising_step(x, one * 0.0, one * 25.0, model=model, b=betas, eta=0, **ls)          # warm-up
     t0 = time.perf_counter()
     for (i, j) in ((0, 25), (25, 51)):
-        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0)
+        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0, **ls)
     t_inv = (time.perf_counter() - t0) / 2
     t0 = time.perf_counter()
     for (i, j) in ((999, 973), (973, 947)):
         x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0, index=0, t_edit=T_EDIT,
-                                          hs_coeff=(1.0, 1.0))
+                                          hs_coeff=(1.0, 1.0), **ls)
     t_gen = (time.perf_counter() - t0) / 2
     per_image = (N_INV - 1) * t_inv + N_GEN * t_gen
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
@@ -78,7 +83,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's: 32 / 64 / 16)")
+    ap.add_argument("--config", choices=["celeba", "church", "afhq", "imagenet"], default="celeba",
+                    help="celeba = BASELINE.json configs[1] (the metric's config, default); church = configs[3] per GPU "
+                         "(same DDPM UNet, batch 256 = 8 x 32); afhq = configs[2] (iDDPM, batch 64); imagenet = "
+                         "configs[4] per GPU (ADM, batch 128 = 8 x 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
@@ -98,13 +107,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from asyrp_official_amd import DDPM, run_edit
+    from asyrp_official_amd import DDPM, i_DDPM, run_edit
     from asyrp_official_amd.diffusion_utils import get_beta_schedule
     from asyrp_official_amd.sampler import gather_shards
 
-    B = a.batch
+    family = {"celeba": "ddpm", "church": "ddpm", "afhq": "afhq", "imagenet": "imagenet"}[a.config]
+    learn_sigma = family != "ddpm"
+    B = a.batch or {"celeba": 32, "church": 32, "afhq": 64, "imagenet": 16}[a.config]
     torch.manual_seed(1234)                     # main.py:301 default seed
-    model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math)
+    if family == "ddpm":
+        model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math)   # configs/church.yml has the same model block
+    else:
+        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=B, conv_math=a.conv_math)
     model.setattr_layers(1)                     # get_h_num = 1
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
@@ -116,7 +130,7 @@ def main():
 
     def one_step():
         x_edit = run_edit(model, x0, betas, n_inv=N_INV, n_gen=N_GEN, t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0,
-                          hs_coeff=(1.0, 1.0))
+                          hs_coeff=(1.0, 1.0), learn_sigma=learn_sigma)
         if world > 1:
             x_edit = gather_shards(x_edit, B * world)   # the one collective of the path
         return x_edit
@@ -155,7 +169,9 @@ def main():
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (conv products on f16 MFMA as exact two-term splits, fp32 accumulate)" if a.conv_math == "f16x3"
             else "f32", "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
-            "config": {"workload": f"CelebA-HQ DDPM 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
+            "config": {"workload": {"celeba": "CelebA-HQ DDPM", "church": "LSUN-Church DDPM", "afhq": "AFHQ-Dog iDDPM",
+                                    "imagenet": "ImageNet ADM (improved_ddpm UNet, 256 base ch)"}[a.config] +
+                                   f" 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
                                    f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
                        "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)"},
         }
@@ -177,7 +193,7 @@ def main():
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, betas)
+            res["cpu_baseline"] = cpu_baseline(cpu_sd, betas, family, learn_sigma)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

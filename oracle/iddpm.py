@@ -28,6 +28,10 @@ AFHQ = IDDPMConfig()                                                    # AFHQ_D
 IMAGENET = IDDPMConfig(num_channels=256, num_res_blocks=2, attention_resolutions=(32, 16, 8), class_cond=True)
 SMALL_I = IDDPMConfig(image_size=32, num_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2),
                       attention_resolutions=(16,), num_head_channels=16)
+# the structural features only IMAGENET_DICT uses, at toy size: two ResBlocks per level, attention at several
+# resolutions (incl. the bottleneck level), class_cond (unused label_emb in the state_dict)
+SMALL_I2 = IDDPMConfig(image_size=32, num_channels=32, num_res_blocks=2, channel_mult=(1, 2, 4),
+                       attention_resolutions=(16, 8), num_head_channels=32, class_cond=True)
 
 
 def block_plan(cfg):

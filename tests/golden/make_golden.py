@@ -194,6 +194,23 @@ def run_iddpm_small(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_iddpm_small2(out):
+    """ImageNet-style structure at toy size (2 ResBlocks/level, attention at 16 and 8, class_cond label_emb)."""
+    from oracle.iddpm import SMALL_I2, iddpm_param_shapes
+    torch.set_num_threads(1)
+    cfg = SMALL_I2
+    sd = synthetic_state_dict(iddpm_param_shapes(cfg, n_delta=1), seed=13)
+    m = ref_iddpm(cfg, sd, 1)
+    x = hash_normal("ismall2.x", (2, 3, 32, 32), seed=3)
+    g = {}
+    with torch.no_grad():
+        t = torch.ones(2) * 555.0
+        et, em, dh, mh = m(x, t, y=torch.tensor([3, 7]), index=0, t_edit=500, hs_coeff=(1.0, 0.8))
+        g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_afhq(out):
     """Full-size AFHQ-dog iDDPM (i_DDPM('AFHQ'), 256x256, B=1): single + dual forward, one learn_sigma Asyrp step.
     Also asserts that guided_Diffusion('MetFACE') (models/guided_diffusion/unet.py) is the same function."""
@@ -239,12 +256,14 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "afhq"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
     if a.only in (None, "iddpm_small"):
         run_iddpm_small(os.path.join(HERE, "iddpm_small.npz"))
+    if a.only in (None, "iddpm_small2"):
+        run_iddpm_small2(os.path.join(HERE, "iddpm_small2.npz"))
     if a.only in (None, "afhq"):
         run_afhq(os.path.join(HERE, "iddpm_afhq.npz"))
     if a.only in (None, "small"):

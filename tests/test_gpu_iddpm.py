@@ -145,3 +145,48 @@ def test_afhq_full_size_forward(conv_math):
                                    b=b, sampling_type="ddim", eta=0.0, learn_sigma=True, index=0, t_edit=444,
                                    hs_coeff=(1.0, 1.0))
     assert_close(xn, ga["step_gen.xt_next"], what="step xt_next")
+
+
+def test_imagenet_style_structure_small():
+    """Two ResBlocks per level, attention at two resolutions incl. the bottleneck level, class_cond label_emb key."""
+    from oracle.iddpm import SMALL_I2
+    g2 = load_golden("iddpm_small2.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(SMALL_I2, n_delta=1), seed=13)
+    m = hip_iddpm(SMALL_I2, sd, 1)
+    x = hash_normal("ismall2.x", (2, 3, 32, 32), seed=3)
+    et, em, dh, mh = m(x.cuda(), torch.ones(2, device="cuda") * 555.0, y=torch.tensor([3, 7]).cuda(), index=0, t_edit=500,
+                       hs_coeff=(1.0, 0.8))
+    for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh), ("fwd_dual.middle_h", mh)):
+        assert_close(got, g2[name], what=name)
+
+
+def test_imagenet_adm_full_size_forward_vs_oracle():
+    """i_DDPM('IMAGENET') (553.8 M params, 1024-ch bottleneck, attention T=1024/256/64 with 64-ch heads), B=1, against the
+    CPU oracle on the same seeded weights (the oracle is pinned by the small reference fixtures)."""
+    from asyrp_official_amd import i_DDPM
+    from oracle.iddpm import IMAGENET
+    gen = torch.Generator().manual_seed(77)
+    sd = {}
+    shapes = iddpm_param_shapes(IMAGENET, n_delta=1)
+    for k, shp in shapes.items():
+        wk = k[:-len(".bias")] + ".weight" if k.endswith(".bias") else k
+        ws = shapes.get(wk, shp)
+        if len(ws) == 1:
+            sd[k] = (1.0 if k.endswith(".weight") else 0.0) + 0.1 * (2 * torch.rand(shp, generator=gen) - 1)
+        else:
+            fan_in = 1
+            for d in ws[1:]:
+                fan_in *= d
+            sd[k] = (2 * torch.rand(shp, generator=gen) - 1) / fan_in ** 0.5
+    m = i_DDPM("IMAGENET", max_batch=1)
+    m.setattr_layers(1)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = torch.randn((1, 3, 256, 256), generator=gen)
+    t = torch.ones(1) * 700.0
+    et, em, dh, mh = m(x.cuda(), t.cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    with torch.no_grad():
+        w_et, w_em, w_dh, w_mh = iddpm_forward(sd, IMAGENET, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    for name, got, want in (("et", et, w_et), ("et_mod", em, w_em), ("delta_h", dh, w_dh), ("middle_h", mh, w_mh)):
+        print(name, err_stats(got, want))
+        assert_close(got, want, what=name)

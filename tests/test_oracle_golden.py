@@ -183,3 +183,16 @@ def test_iddpm_full_size_afhq_against_reference():
     assert_close(et, g["fwd_dual.et"], what="et", rtol=1e-4, atol=1e-5)
     assert_close(em, g["fwd_dual.et_mod"], what="et_mod", rtol=1e-4, atol=1e-5)
     assert_close(dh, g["fwd_dual.delta_h"], what="delta_h", rtol=1e-4, atol=1e-5)
+
+
+def test_iddpm_imagenet_style_structure():
+    from conftest import load_golden
+    from oracle.iddpm import SMALL_I2, iddpm_forward, iddpm_param_shapes
+    g = load_golden("iddpm_small2.npz")
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(iddpm_param_shapes(SMALL_I2, n_delta=1), seed=13)
+    x = hash_normal("ismall2.x", (2, 3, 32, 32), seed=3)
+    with torch.no_grad():
+        et, em, dh, mh = iddpm_forward(sd, SMALL_I2, x, torch.ones(2) * 555.0, index=0, t_edit=500, hs_coeff=(1.0, 0.8))
+    for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh), ("fwd_dual.middle_h", mh)):
+        assert_close(got, g[name], what=name, **ITIGHT)
