@@ -190,8 +190,19 @@ def main():
                                "x_fp32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS, "kernel": prof["kernel"],
                                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / prof["launches"],
                                "flops_per_launch": prof["flops"] / prof["launches"],
+                               "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of
+        # this same command (scripts/gpu_traffic.sh -> profiles/traffic_main_tile.json) are reported per launch
+        tpath = os.path.join(ROOT, "profiles", "traffic_main_tile.json")
+        if "roofline" in res and a.config == "celeba" and B == 32 and os.path.exists(tpath):
+            tr = json.load(open(tpath))
+            if tr.get("kernel") == res["roofline"]["kernel"]:
+                res["roofline"]["traffic"] = 1024.0 * (2.0 * tr["FETCH_SIZE_KB_per_launch"] + tr["WRITE_SIZE_KB_per_launch"])
+                res["roofline"]["traffic_note"] = ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC passes "
+                                                   f"({tr['round']}); x2 = gfx950 FETCH_SIZE correction; compare with "
+                                                   "algorithmic_bytes_per_launch")
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, betas, family, learn_sigma)
         print(json.dumps(res), flush=True)
