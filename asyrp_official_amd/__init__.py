@@ -12,6 +12,7 @@ from .improved_ddpm import UNetModel, create_model, guided_Diffusion, i_DDPM  # 
 from .diffusion_utils import denoising_step, extract, get_beta_schedule  # noqa: F401
 from .engine import AsyrpDeviceError, Engine  # noqa: F401
 from .sampler import gather_shards, run_edit, run_edit_sharded, shard_bounds, timestep_seq  # noqa: F401
+from . import cache  # noqa: F401  (latent-cache / Δh-checkpoint formats, hs_coeff schedules)
 
 __all__ = ["DDPM", "UNetModel", "create_model", "i_DDPM", "guided_Diffusion", "denoising_step", "extract", "get_beta_schedule", "run_edit", "run_edit_sharded",
            "timestep_seq", "shard_bounds", "gather_shards", "Engine", "AsyrpDeviceError"]

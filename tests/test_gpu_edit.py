@@ -149,3 +149,32 @@ def test_sharded_equals_unsharded_bitwise(small):
     full = run_edit(m, xs, b, n_inv=4, n_gen=4, t_edit=500)
     parts = [run_edit(m, xs[lo:hi].contiguous(), b, n_inv=4, n_gen=4, t_edit=500) for lo, hi in ((0, 2), (2, 3))]
     assert torch.equal(full, torch.cat(parts))
+
+
+def test_precompute_pairs_and_strength_sweep(small, tmp_path):
+    """§8(f): PHASE A as a batch (x_lat + plain-DDIM reconstruction x_rec in the reference's pairs format) and a
+    --delta_interpolation style sweep of hs_coeff from the cached latents."""
+    from asyrp_official_amd import cache
+    m, sd, x = small
+    b = osamp.beta_schedule()
+    model = osamp.make_model(sd, SMALL)
+    pairs = cache.precompute_pairs(m, x.cuda(), b, n_inv=6)
+    assert len(pairs) == 2 and all(t.shape == (1, 3, 32, 32) and not t.is_cuda for tr in pairs for t in tr)
+    w_lat = osamp.invert(model, x, b, n_inv=6)
+    w_rec = osamp.generate(model, w_lat, b, n_gen=6, index=None)
+    got_lat = torch.cat([p[2] for p in pairs])
+    got_rec = torch.cat([p[1] for p in pairs])
+    assert_close(got_lat, w_lat, what="x_lat")
+    st = err_stats(got_rec, w_rec)
+    print("x_rec", st)
+    assert st["max_abs"] <= 1e-4 * max(1.0, st["ref_absmax"])
+    path = cache.pairs_path("CelebA_HQ", "test", 999, 2, 6, root=str(tmp_path))
+    cache.save_pairs(path, pairs)
+    _, x_lat = cache.latents_from_pairs(cache.load_pairs(path), device="cuda")
+    coeffs = cache.delta_interpolation_coeffs(0.0, 1.0, 2)
+    outs = cache.edit_sweep(m, x_lat, b, coeffs, n_gen=6, t_edit=500)
+    for hc, got in zip(coeffs, outs):
+        want = osamp.generate(model, x_lat.cpu(), b, n_gen=6, t_edit=500, hs_coeff=hc)
+        st = err_stats(got, want)
+        print(hc, st)
+        assert st["max_abs"] <= 1e-4 * max(1.0, st["ref_absmax"]) and st["frac_outside"] <= 0.02

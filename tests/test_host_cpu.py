@@ -161,3 +161,40 @@ def test_shipped_iddpm_delta_checkpoints_load_unmodified():
         assert not res.missing_keys and not res.unexpected_keys
         n += 1
     assert n >= 5
+
+
+def test_cache_formats_roundtrip_and_reference_names(tmp_path):
+    """§8(f)-1: the latent-cache and Δh-checkpoint files are the reference's own formats and names."""
+    from asyrp_official_amd import DDPM, cache
+    assert cache.pairs_path("CelebA_HQ", "test", 999, 4, 40) == "precomputed/CelebA_HQ_test_t999_nim4_ninv40_pairs.pth"
+    assert cache.checkpoint_name("smiling", "CelebA_HQ", 999, 40, 40) == "checkpoint/smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth"
+    pairs = [[torch.randn(1, 3, 8, 8) for _ in range(3)] for _ in range(3)]
+    p = os.path.join(tmp_path, "precomputed", "x_pairs.pth")
+    cache.save_pairs(p, pairs)
+    back = torch.load(p, map_location="cpu", weights_only=False)          # exactly what diffusion_latent.py:977 does
+    assert isinstance(back, list) and len(back) == 3 and all(len(t) == 3 for t in back)
+    assert all(torch.equal(a, b) for ta, tb in zip(pairs, cache.load_pairs(p)) for a, b in zip(ta, tb))
+    x0, x_lat = cache.latents_from_pairs(back, 1, 3)
+    assert x0.shape == (2, 3, 8, 8) and torch.equal(x_lat[0], pairs[1][2][0])
+    m = DDPM(namespace_for(SMALL), max_batch=1)
+    m.setattr_layers(2)
+    ck = os.path.join(tmp_path, "checkpoint", "a_0.pth")
+    cache.save_delta_checkpoint(m, ck, get_h_num=2)
+    d = torch.load(ck, map_location="cpu", weights_only=False)
+    assert set(d.keys()) == {"0", "1", "optimizer", "scheduler"}
+    assert set(d["0"].keys()) == {"conv1.weight", "conv1.bias", "temb_proj.weight", "temb_proj.bias", "norm2.weight",
+                                  "norm2.bias", "conv2.weight", "conv2.bias"}
+    m2 = DDPM(namespace_for(SMALL), max_batch=1)
+    m2.setattr_layers(2)
+    cache.load_delta_checkpoints(m2, [ck, ck])       # multiple_attr: one file per DeltaBlock, key "0" of each (:674-676)
+    assert torch.equal(m2.layer_1.conv2.weight, m.layer_0.conv2.weight)
+
+
+def test_hs_coeff_schedules_match_reference_formulas():
+    from asyrp_official_amd import cache
+    assert cache.make_hs_coeff(40, 40) == (1.0, 1.0)
+    assert cache.make_hs_coeff(40, 20, hs_coeff_delta_h=1.5) == (1.0, 3.0)                     # :626, :659
+    hc = cache.make_hs_coeff(40, 40, multiple_hs_coeff=[0.5], n_attr=2)                      # :654
+    assert hc[0] == 1.0 and abs(hc[1] - 0.5 / 2 ** 0.5) < 1e-12 and abs(hc[2] - 1 / 2 ** 0.5) < 1e-12
+    sw = cache.delta_interpolation_coeffs(-1.0, 1.0, 5)
+    assert [c[1] for c in sw] == [-1.0, -0.5, 0.0, 0.5, 1.0] and all(c[0] == 1.0 for c in sw)
