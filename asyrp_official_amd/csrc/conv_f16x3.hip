@@ -36,9 +36,10 @@ constexpr float ACT_SCALE = 1.0f;       // optional power-of-two pre-scale of th
                                         // O(1) activations keep fp32-class accuracy without the extra multiply
 constexpr float H_MAX = 65504.0f;
 
-template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_>
+template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_, int RB_ = 2>
 struct XCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, KS = KS_, STRIDE = STRIDE_;
+  static constexpr int RB = RB_;                       // weight-slice ring size: a slice is in flight for RB-1 K-steps
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static constexpr int PW = (KS == 1) ? BM : (BM >= 128 ? 16 : 8);
@@ -51,7 +52,8 @@ struct XCfg {
   static constexpr int NA = (NU + NT - 1) / NT;
   static constexpr int NTAPS = KS * KS;
   static constexpr int NPIECE = 4 * BN / 64;           // 1-KiB LDS-DMA pieces per B slice
-  static constexpr size_t SMEM = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES;
+  static constexpr size_t SMEM = 2 * (size_t)A_BYTES + RB * (size_t)B_BYTES;
+  static constexpr int NPW = (NPIECE + NW - 1) / NW;   // LDS-DMA instructions each wave issues per slice
   // workgroups per CU the LDS admits x waves per workgroup / 4 SIMDs = waves per SIMD to budget registers for
   static constexpr int MINW = ((SMEM <= 76 * 1024) ? 2 : 1) * (NW / 4);
 };
@@ -280,13 +282,17 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const int nsteps = nchunks * NTAPS;
 
   if (PIPE) {
-    // ---- prologue: chunk 0 + weight slice 0 staged, slice 1 in flight, fragments of step 0 in registers ----
+    constexpr int RB = T::RB, NPW = T::NPW;
+    static_assert(T::NPIECE % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slice (counted vmcnt)");
+    // ---- prologue: chunk 0 + weight slice 0 staged, slices 1..RB-1 in flight, fragments of step 0 in registers ----
     issue_B(0, 0);
     gload_A(0);
     write_A(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nsteps > 1) issue_B(1, 1);
+#pragma unroll
+    for (int j = 1; j < RB; ++j)
+      if (j < nsteps) issue_B(j, j);
     if (NTAPS == 1 && nchunks > 1) gload_A(1);   // 1x1: chunk 1 is written during step 0
     h8 ah[TM], al[TM], bh[TN], bl[TN];
     {
@@ -297,16 +303,15 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
     }
-    int chunk = 0, tap = 0;
+    int chunk = 0, tap = 0, slot = 0;   // slot = step % RB
     for (int step = 0; step < nsteps; ++step) {
       const bool last_tap = (tap == NTAPS - 1);
       const bool next_a = (chunk + 1 < nchunks);
       const int ky = tap / KS, kx = tap - ky * KS;
       const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
-      const char* B = Bs + (step & 1) * B_BYTES + boff;
+      const char* B = Bs + slot * B_BYTES + boff;
       // the step opens with matrix work on register-resident fragments; this step's x_hi / w_lo reads are issued behind
       // the first MFMA (pinned: the compiler's lgkmcnt wait for al/bh must not sit behind freshly issued reads)
-      if (PRIO) __builtin_amdgcn_s_setprio(1);   // the two workgroups of a CU are in different phases: favour the one doing matrix work
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -323,20 +328,30 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
       // next chunk's halo tile (loaded one step ago or earlier) -> LDS, before the barrier that publishes it
       if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight slice step+1 has landed
-      __syncthreads();                                     // ... and every wave's reads of slice `step` are complete
+      // Slice step+1 must have landed; the newer slices step+2 .. step+RB-1 (NPW LDS-DMA instructions each, fewer at the
+      // tail) stay in flight across the barrier.  Activation loads issued after slice step+1 only make the wait stricter.
+      {
+        const int lastq = (step + RB - 1 < nsteps - 1) ? step + RB - 1 : nsteps - 1;
+        const int newer = lastq - (step + 1);
+        if (RB >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+        else if (RB >= 3 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes (halo tile) and reads of slice `step` are complete
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       int nchunk = chunk, ntap = tap + 1;
       if (ntap == NTAPS) { ntap = 0; ++nchunk; }
-      if (step + 2 < nsteps) issue_B(step + 2, step & 1);
+      const int nslot = (slot + 1 == RB) ? 0 : slot + 1;
+      if (step + RB < nsteps) issue_B(step + RB, slot);   // slot of slice `step`: every wave's reads of it are complete
       // activation loads for the chunk after step+1's: issued a full step (3x3: eight steps) before their staging pass
       if (ntap == (NTAPS > 1 ? 1 : 0) && nchunk + 1 < nchunks) gload_A(nchunk + 1);
       if (step + 1 < nsteps) {
         const int nky = ntap / KS, nkx = ntap - nky * KS;
         const char* An = As + (nchunk & 1) * A_BYTES + (kh * NPIX + nky * TW + nkx) * 16;
-        const char* Bn = Bs + ((step + 1) & 1) * B_BYTES + boff;
+        const char* Bn = Bs + nslot * B_BYTES + boff;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(An + apix[tm] * 16 + 2 * NPIX * 16);
 #pragma unroll
@@ -349,6 +364,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
       tap = ntap;
       chunk = nchunk;
+      slot = nslot;
     }
   } else {
     // ---- prologue: stage chunk 0 and the first weight slice ----
@@ -623,14 +639,14 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: bm = 256; break;
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: bm = 256; break;
     case XT_128x128: bm = 128; break;
     default: bm = 64;
   }
@@ -644,26 +660,35 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;
   if (a.ks == 1 && (a.stride != 1 || a.ups)) return hipErrorInvalidValue;
   const int tile = eff_tile_x(a);
-  using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1>;
-  using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1>;
-  using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1>;
-  using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1>;
-  using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1>;
+  // last parameter: weight-slice ring size of the pipelined loop (slices stay in flight for RB-1 K-steps); the small
+  // tiles have short K-steps (3-6 MFMAs per wave), so they need the deeper ring to cover the L2 latency of a slice
+  using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1, 3>;
+  using X256x128_3r2 = XCfg<4, 1, 2, 4, 3, 1, 2>;
+  using X256x128_3r4 = XCfg<4, 1, 2, 4, 3, 1, 4>;
+  using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1, 4>;
+  using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1, 4>;
+  using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 4>;
+  using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
-  using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2>;
-  using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1>;
-  using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1>;
-  using X64x128_1 = XCfg<2, 2, 1, 2, 1, 1>;
-  using X64x64_1 = XCfg<2, 2, 1, 1, 1, 1>;
-  using X256x64_1 = XCfg<4, 1, 2, 2, 1, 1>;
+  using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
+  using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 3>;
+  using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1, 4>;
+  using X64x128_1 = XCfg<2, 2, 1, 2, 1, 1, 4>;
+  using X64x64_1 = XCfg<2, 2, 1, 1, 1, 1, 4>;
+  using X256x64_1 = XCfg<4, 1, 2, 2, 1, 1, 4>;
+  using X256x128_3plain = XCfg<4, 1, 2, 4, 3, 1>;   // un-pipelined loop (ragged-channel staging, ablation build)
+  using X64x128_3plain = XCfg<2, 2, 1, 2, 3, 1>;
+  using X64x128_3s2plain = XCfg<2, 2, 1, 2, 3, 2>;
+  using X256x128_1plain = XCfg<4, 1, 2, 4, 1, 1>;
+  using X64x128_1plain = XCfg<2, 2, 1, 2, 1, 1>;
   if (!is_vec(a)) {   // ragged channel counts (conv_in: Cin = 3): scalar-gather staging, two tile shapes per kernel size
-    if (a.stride == 2) return launch_x<X64x128_3s2, false>(a, s);
+    if (a.stride == 2) return launch_x<X64x128_3s2plain, false>(a, s);
     const bool big = (tile == XT_256x128);
-    if (a.ks == 3) return big ? launch_x<X256x128_3, false>(a, s) : launch_x<X64x128_3, false>(a, s);
-    return big ? launch_x<X256x128_1, false>(a, s) : launch_x<X64x128_1, false>(a, s);
+    if (a.ks == 3) return big ? launch_x<X256x128_3plain, false>(a, s) : launch_x<X64x128_3plain, false>(a, s);
+    return big ? launch_x<X256x128_1plain, false>(a, s) : launch_x<X64x128_1plain, false>(a, s);
   }
   if (a.abl) {   // profiling build of the main tile only
-    if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3plain, true, true>(a, s);
     return hipErrorInvalidValue;
   }
   if (a.ks == 3) {
@@ -675,7 +700,8 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, true>(a, s);   // A/B: + s_setprio
+      case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 2
+      case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
     }
   } else {
     switch (tile) {

@@ -52,11 +52,11 @@ if __name__ == "__main__":
         for math in ("f16x3",):
             ms, tf = run(H, C0, C1, Co, k, math=math, **kw)
             print(f"{name:40s} {math:6s} {ms:8.3f} ms {tf:7.1f} TFLOP/s", flush=True)
-    print("-- A/B interleaved: tile 1 (pipelined) vs tile 7 (pipelined + s_setprio), 5 rounds")
+    print("-- A/B interleaved: weight-slice ring of 3 (tile 1) vs 2 (tile 7) vs 4 (tile 8), 4 rounds")
     for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
-        for rnd in range(5):
-            r = [run(H, Ch, C1, Ch, 3, tile=t, iters=6)[1] for t in (1, 7)]
-            print(f"  {Ch}+{C1}->{Ch} @{H} round {rnd}: tile1 {r[0]:6.1f}  tile7 {r[1]:6.1f} TFLOP/s", flush=True)
+        for rnd in range(4):
+            r = [run(H, Ch, C1, Ch, 3, tile=t, iters=6)[1] for t in (1, 7, 8)]
+            print(f"  {Ch}+{C1}->{Ch} @{H} round {rnd}: ring3 {r[0]:6.1f}  ring2 {r[1]:6.1f}  ring4 {r[2]:6.1f} TFLOP/s", flush=True)
     print("-- tile sweep, 128->128 @64 and 512->512 @16 (f16x3)")
     for (H, Ch) in ((256, 128), (64, 256), (16, 512), (8, 512), (32, 256)):
         for tile in (1, 2, 3, 4, 6):
