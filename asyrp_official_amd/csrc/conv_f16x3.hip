@@ -36,10 +36,13 @@ constexpr float ACT_SCALE = 1.0f;       // optional power-of-two pre-scale of th
                                         // O(1) activations keep fp32-class accuracy without the extra multiply
 constexpr float H_MAX = 65504.0f;
 
-template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_, int RB_ = 2>
+template <int WM_, int WN_, int TM_, int TN_, int KS_, int STRIDE_, int RB_ = 2, int TS_ = 1>
 struct XCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, KS = KS_, STRIDE = STRIDE_;
-  static constexpr int RB = RB_;                       // weight-slice ring size: a slice is in flight for RB-1 K-steps
+  static constexpr int RB = RB_;                       // weight-slice ring size: a slice is in flight for RB-1 barriers
+  static constexpr int TS = TS_;                       // taps per barrier ("fat" K-step): one ring slot holds TS consecutive
+                                                       // tap slices of a chunk; 3 on the small tiles whose single-tap steps
+                                                       // (3-12 MFMAs per wave) are shorter than a barrier round trip
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static constexpr int PW = (KS == 1) ? BM : (BM >= 128 ? 16 : 8);
@@ -52,8 +55,8 @@ struct XCfg {
   static constexpr int NA = (NU + NT - 1) / NT;
   static constexpr int NTAPS = KS * KS;
   static constexpr int NPIECE = 4 * BN / 64;           // 1-KiB LDS-DMA pieces per B slice
-  static constexpr size_t SMEM = 2 * (size_t)A_BYTES + RB * (size_t)B_BYTES;
-  static constexpr int NPW = (NPIECE + NW - 1) / NW;   // LDS-DMA instructions each wave issues per slice
+  static constexpr size_t SMEM = 2 * (size_t)A_BYTES + RB * (size_t)B_BYTES * TS;
+  static constexpr int NPW = (TS * NPIECE + NW - 1) / NW;   // LDS-DMA instructions each wave issues per ring slot
   // workgroups per CU the LDS admits x waves per workgroup / 4 SIMDs = waves per SIMD to budget registers for
   static constexpr int MINW = ((SMEM <= 76 * 1024) ? 2 : 1) * (NW / 4);
 };
@@ -282,17 +285,33 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const int nsteps = nchunks * NTAPS;
 
   if (PIPE) {
-    constexpr int RB = T::RB, NPW = T::NPW;
-    static_assert(T::NPIECE % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slice (counted vmcnt)");
-    // ---- prologue: chunk 0 + weight slice 0 staged, slices 1..RB-1 in flight, fragments of step 0 in registers ----
-    issue_B(0, 0);
+    constexpr int RB = T::RB, NPW = T::NPW, TS = T::TS;
+    constexpr int SLOT_BYTES = TS * B_BYTES;
+    static_assert((TS * T::NPIECE) % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slot (counted vmcnt)");
+    static_assert(NTAPS % TS == 0, "a fat step must not straddle two channel chunks");
+    // one ring slot = TS consecutive tap slices (they are consecutive in the packed weight image)
+    auto issue_slot = [&](int fs, int slot) {
+#pragma unroll
+      for (int pc0 = 0; pc0 < TS * NPIECE; pc0 += NW) {
+        const int pc = pc0 + wave;
+        const int tt = pc / NPIECE, q = pc - tt * NPIECE;
+        const int u = q / (BN / 64), part = q - u * (BN / 64);
+        const char* src = wpk + ((long long)((fs * TS + tt) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
+        char* dst = Bs + slot * SLOT_BYTES + tt * B_BYTES + (u * BN + part * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    const int nfat = nsteps / TS;
+    // ---- prologue: chunk 0 + weight slot 0 staged, slots 1..RB-1 in flight, fragments of step 0 in registers ----
+    issue_slot(0, 0);
     gload_A(0);
     write_A(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int j = 1; j < RB; ++j)
-      if (j < nsteps) issue_B(j, j);
+      if (j < nfat) issue_slot(j, j);
     if (NTAPS == 1 && nchunks > 1) gload_A(1);   // 1x1: chunk 1 is written during step 0
     h8 ah[TM], al[TM], bh[TN], bl[TN];
     {
@@ -303,13 +322,14 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
     }
-    int chunk = 0, tap = 0, slot = 0;   // slot = step % RB
+    int chunk = 0, tap = 0, slot = 0, tt = 0, fs = 0;   // slot = fs % RB, tt = step % TS
     for (int step = 0; step < nsteps; ++step) {
       const bool last_tap = (tap == NTAPS - 1);
       const bool next_a = (chunk + 1 < nchunks);
+      const bool endfat = (tt == TS - 1);
       const int ky = tap / KS, kx = tap - ky * KS;
       const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
-      const char* B = Bs + slot * B_BYTES + boff;
+      const char* B = Bs + slot * SLOT_BYTES + tt * B_BYTES + boff;
       // the step opens with matrix work on register-resident fragments; this step's x_hi / w_lo reads are issued behind
       // the first MFMA (pinned: the compiler's lgkmcnt wait for al/bh must not sit behind freshly issued reads)
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[0], acc[0][0], 0, 0, 0);
@@ -328,30 +348,34 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      // next chunk's halo tile (loaded one step ago or earlier) -> LDS, before the barrier that publishes it
-      if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
-      // Slice step+1 must have landed; the newer slices step+2 .. step+RB-1 (NPW LDS-DMA instructions each, fewer at the
-      // tail) stay in flight across the barrier.  Activation loads issued after slice step+1 only make the wait stricter.
-      {
-        const int lastq = (step + RB - 1 < nsteps - 1) ? step + RB - 1 : nsteps - 1;
-        const int newer = lastq - (step + 1);
-        if (RB >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-        else if (RB >= 3 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes (halo tile) and reads of slice `step` are complete
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
       int nchunk = chunk, ntap = tap + 1;
       if (ntap == NTAPS) { ntap = 0; ++nchunk; }
-      const int nslot = (slot + 1 == RB) ? 0 : slot + 1;
-      if (step + RB < nsteps) issue_B(step + RB, slot);   // slot of slice `step`: every wave's reads of it are complete
+      int nslot = slot, ntt = tt + 1;
+      if (endfat) {
+        // next chunk's halo tile (loaded a step or more ago) -> LDS, before the barrier that publishes it
+        if (last_tap && next_a) write_A(chunk + 1, (chunk + 1) & 1);
+        // Slot fs+1 must have landed; the newer slots fs+2 .. fs+RB-1 (NPW LDS-DMA instructions each, fewer at the tail) stay
+        // in flight across the barrier.  Activation loads issued after slot fs+1 only make the wait stricter.
+        {
+          const int lastq = (fs + RB - 1 < nfat - 1) ? fs + RB - 1 : nfat - 1;
+          const int newer = lastq - (fs + 1);
+          if (RB >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+          else if (RB >= 3 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes (halo tile) and reads of slot `fs` are complete
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (fs + RB < nfat) issue_slot(fs + RB, slot);       // slot of fat step `fs`: every wave's reads of it are complete
+        nslot = (slot + 1 == RB) ? 0 : slot + 1;
+        ntt = 0;
+      }
       // activation loads for the chunk after step+1's: issued a full step (3x3: eight steps) before their staging pass
       if (ntap == (NTAPS > 1 ? 1 : 0) && nchunk + 1 < nchunks) gload_A(nchunk + 1);
       if (step + 1 < nsteps) {
         const int nky = ntap / KS, nkx = ntap - nky * KS;
         const char* An = As + (nchunk & 1) * A_BYTES + (kh * NPIX + nky * TW + nkx) * 16;
-        const char* Bn = Bs + nslot * B_BYTES + boff;
+        const char* Bn = Bs + nslot * SLOT_BYTES + ntt * B_BYTES + boff;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(An + apix[tm] * 16 + 2 * NPIX * 16);
 #pragma unroll
@@ -364,7 +388,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
       tap = ntap;
       chunk = nchunk;
+      if (endfat) ++fs;
       slot = nslot;
+      tt = ntt;
     }
   } else {
     // ---- prologue: stage chunk 0 and the first weight slice ----
@@ -624,8 +650,10 @@ static int auto_tile_x(const GemmArgs& a) {
   };
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
   if (M >= 256 && blocks(256, 128) >= 512) return XT_256x128;
-  if (M >= 128 && blocks(128, 128) >= 384) return XT_128x128;
-  if (blocks(64, 128) >= 256) return XT_64x128;
+  // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
+  // (measured, profiles/r01_conv_microbench_*.txt); 8x8 layers (M = 64) fall through to 64-pixel tiles
+  if (M >= 128 && blocks(128, 128) >= 256) return XT_128x128;
+  if (M >= 128 && blocks(64, 128) >= 256) return XT_64x128;
   return XT_64x64;
 }
 
@@ -647,7 +675,7 @@ int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: bm = 256; break;
-    case XT_128x128: bm = 128; break;
+    case XT_128x128: case 9: bm = 128; break;
     default: bm = 64;
   }
   if (a.ks == 1) return (a.Hout * a.Wout + bm - 1) / bm;
@@ -665,9 +693,12 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1, 3>;
   using X256x128_3r2 = XCfg<4, 1, 2, 4, 3, 1, 2>;
   using X256x128_3r4 = XCfg<4, 1, 2, 4, 3, 1, 4>;
-  using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1, 4>;
-  using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1, 4>;
-  using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 4>;
+  using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1, 2, 3>;    // 11.5 KB x 2 halo + 2 x 24 KB weight slots = 71 KB: 2 workgroups per CU
+  using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1, 2, 3>;     // 61 KB
+  using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 3, 3>;      // 49 KB
+  using X128x128_3t1 = XCfg<2, 2, 2, 2, 3, 1, 4>;     // single-tap variants kept for A/B (tile ids 9..11)
+  using X64x128_3t1 = XCfg<2, 2, 1, 2, 3, 1, 4>;
+  using X64x64_3t1 = XCfg<2, 2, 1, 1, 3, 1, 4>;
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
@@ -702,6 +733,9 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
       case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 2
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
+      case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);
+      case 10: return launch_x<X64x128_3t1, true, false, true>(a, s);
+      case 11: return launch_x<X64x64_3t1, true, false, true>(a, s);
     }
   } else {
     switch (tile) {
