@@ -49,6 +49,7 @@ _SIGS = {
     "asyrp_op_conv2d": (C.c_int, [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P,
                                   _P, _I, _I, _P]),
     "asyrp_op_conv2d_stats": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
+    "asyrp_op_resblock_tail": (C.c_int, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P, _P]),
     "asyrp_op_conv_bench": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P]),
     "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P]),
 }

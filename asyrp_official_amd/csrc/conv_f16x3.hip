@@ -96,7 +96,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // PIPE: software-pipelined K-loop (4-wave tiles): the per-step barrier sits between MFMA pass 2 and pass 3, the next
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool PRIO = false>
+// SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (PIPE, TS=1)
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
   const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
   const int Cin = p.Cin, Cout = p.Cout, c0 = p.c0;
+  const int nch1 = (Cin + XKC - 1) / XKC;   // chunks of the conv proper (the fused shortcut's chunks follow)
 
   // ---- A staging map: work item u = (pixel, 8-channel half); NT is even so the half is per-thread constant ----
   const int hf = tid & 1;
@@ -161,16 +163,25 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   auto gload_A = [&](int chunk) {
     const int c = chunk * XKC + hf * 8;
     if (VEC) {
-      if (ps) {
-        sreg[0] = *reinterpret_cast<const float4*>(ps + c);
-        sreg[1] = *reinterpret_cast<const float4*>(ps + c + 4);
-        sreg[2] = *reinterpret_cast<const float4*>(psh + c);
-        sreg[3] = *reinterpret_cast<const float4*>(psh + c + 4);
+      const float* __restrict__ base;
+      int ld;
+      if (SC && chunk >= nch1) {   // shortcut phase: raw (s0|s1), no prologue
+        const int cc = (chunk - nch1) * XKC + hf * 8;
+        const bool second = ((chunk - nch1) * XKC >= p.sc0);
+        base = second ? p.s1 + (long long)zo * p.s1_zo + (cc - p.sc0) : p.s0 + (long long)zo * p.s0_zo + cc;
+        ld = second ? p.lds1 : p.lds0;
+      } else {
+        if (ps) {
+          sreg[0] = *reinterpret_cast<const float4*>(ps + c);
+          sreg[1] = *reinterpret_cast<const float4*>(ps + c + 4);
+          sreg[2] = *reinterpret_cast<const float4*>(psh + c);
+          sreg[3] = *reinterpret_cast<const float4*>(psh + c + 4);
+        }
+        // the whole chunk lies in one source (c0 % 16 == 0): block-uniform select
+        const bool second = (chunk * XKC >= c0);
+        base = second ? a1 + (c - c0) : a0 + c;
+        ld = second ? p.lda1 : p.lda0;
       }
-      // the whole chunk lies in one source (c0 % 16 == 0): block-uniform select
-      const bool second = (chunk * XKC >= c0);
-      const float* __restrict__ base = second ? a1 + (c - c0) : a0 + c;
-      const int ld = second ? p.lda1 : p.lda0;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
@@ -219,7 +230,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       if (aoff[i] == -2) continue;
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
-      if (aoff[i] >= 0 && !(abl & 1)) {
+      if (aoff[i] >= 0 && !(abl & 1) && !(SC && chunk >= nch1)) {
         // block-uniform prologue mode hoisted out of the element loop (no per-element selects)
         if (ps) {
 #pragma unroll
@@ -281,14 +292,15 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  const int nchunks = (Cin + XKC - 1) / XKC;
-  const int nsteps = nchunks * NTAPS;
+  const int nchunks = nch1 + (SC ? p.Cin2 / XKC : 0);
+  const int nsteps = nch1 * NTAPS + (SC ? p.Cin2 / XKC : 0);
 
   if (PIPE) {
     constexpr int RB = T::RB, NPW = T::NPW, TS = T::TS;
     constexpr int SLOT_BYTES = TS * B_BYTES;
     static_assert((TS * T::NPIECE) % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slot (counted vmcnt)");
     static_assert(NTAPS % TS == 0, "a fat step must not straddle two channel chunks");
+    static_assert(!SC || TS == 1, "the fused shortcut's single-tap chunks need single-tap steps");
     // one ring slot = TS consecutive tap slices (they are consecutive in the packed weight image)
     auto issue_slot = [&](int fs, int slot) {
 #pragma unroll
@@ -324,10 +336,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     }
     int chunk = 0, tap = 0, slot = 0, tt = 0, fs = 0;   // slot = fs % RB, tt = step % TS
     for (int step = 0; step < nsteps; ++step) {
-      const bool last_tap = (tap == NTAPS - 1);
+      const int ntaps_c = (SC && chunk >= nch1) ? 1 : NTAPS;   // shortcut chunks have the centre tap only
+      const bool last_tap = (tap == ntaps_c - 1);
       const bool next_a = (chunk + 1 < nchunks);
       const bool endfat = (tt == TS - 1);
-      const int ky = tap / KS, kx = tap - ky * KS;
+      const int tapA = (SC && chunk >= nch1) ? (NTAPS / 2) : tap;
+      const int ky = tapA / KS, kx = tapA - ky * KS;
       const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
       const char* B = Bs + slot * SLOT_BYTES + tt * B_BYTES + boff;
       // the step opens with matrix work on register-resident fragments; this step's x_hi / w_lo reads are issued behind
@@ -349,7 +363,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
       int nchunk = chunk, ntap = tap + 1;
-      if (ntap == NTAPS) { ntap = 0; ++nchunk; }
+      if (ntap == ntaps_c) { ntap = 0; ++nchunk; }
       int nslot = slot, ntt = tt + 1;
       if (endfat) {
         // next chunk's halo tile (loaded a step or more ago) -> LDS, before the barrier that publishes it
@@ -371,9 +385,13 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         ntt = 0;
       }
       // activation loads for the chunk after step+1's: issued a full step (3x3: eight steps) before their staging pass
-      if (ntap == (NTAPS > 1 ? 1 : 0) && nchunk + 1 < nchunks) gload_A(nchunk + 1);
+      {
+        const int trig = (NTAPS > 1 && !(SC && nchunk >= nch1)) ? 1 : 0;
+        if (ntap == trig && nchunk + 1 < nchunks) gload_A(nchunk + 1);
+      }
       if (step + 1 < nsteps) {
-        const int nky = ntap / KS, nkx = ntap - nky * KS;
+        const int ntapA = (SC && nchunk >= nch1) ? (NTAPS / 2) : ntap;
+        const int nky = ntapA / KS, nkx = ntapA - nky * KS;
         const char* An = As + (nchunk & 1) * A_BYTES + (kh * NPIX + nky * TW + nkx) * 16;
         const char* Bn = Bs + nslot * SLOT_BYTES + ntt * B_BYTES + boff;
 #pragma unroll
@@ -613,7 +631,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool PRIO = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -625,12 +643,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, PRIO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, PRIO>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -669,6 +687,12 @@ static int eff_tile_x(const GemmArgs& a) {
   if (is_vec(a)) return t;
   return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4) ? XT_256x128
                                                                                                                : XT_64x128;
+}
+
+bool gemm_can_fuse_shortcut(const GemmArgs& a) {
+  if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
+  if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
+  return is_vec(a) && eff_tile_x(a) == XT_256x128;
 }
 
 int gemm_mblocks(const GemmArgs& a) {
@@ -721,6 +745,10 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   if (a.abl) {   // profiling build of the main tile only
     if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3plain, true, true>(a, s);
     return hipErrorInvalidValue;
+  }
+  if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
+    if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
+    return launch_x<X256x128_3, true, false, true, true>(a, s);
   }
   if (a.ks == 3) {
     if (a.stride == 2) return launch_x<X64x128_3s2, true, false, true>(a, s);

@@ -393,6 +393,44 @@ int pack_x3(asyrp_engine* e, const std::string& name, const std::vector<float>& 
   return 0;
 }
 
+// 3x3 conv weight + the block's 1x1 shortcut weight -> ONE f16x3 image: the shortcut's slices follow the conv's K-steps
+// (conv_f16x3.hip, fused shortcut); one common power-of-two scale.  Stored under `name` + "#sc".
+int pack_x3_fused(asyrp_engine* e, const std::string& name, const std::vector<float>& w3, int cout, int cin3,
+                  const std::vector<float>& w1, int cin1) {
+  float mx = 0.f;
+  for (float v : w3) mx = std::max(mx, std::fabs(v));
+  for (float v : w1) mx = std::max(mx, std::fabs(v));
+  float wscale = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx)));
+  const size_t h3 = f16x3_packed_halfs(cout, cin3, 3), h1 = f16x3_packed_halfs(cout, cin1, 1);
+  const std::string key = name + "#sc";
+  asyrp_engine::XW x;
+  auto it = e->xw.find(key);
+  if (it != e->xw.end() && it->second.halfs == h3 + h1) {
+    x = it->second;
+  } else {
+    if (it != e->xw.end()) { (void)hipFree(it->second.p); e->param_bytes -= it->second.halfs * 2; }
+    HIPCHK(hipMalloc(&x.p, (h3 + h1) * 2));
+    x.halfs = h3 + h1;
+    e->param_bytes += (h3 + h1) * 2;
+  }
+  x.wscale = wscale;
+  x.cout_pad = ((cout + 127) / 128) * 128;
+  float *t3 = nullptr, *t1 = nullptr;
+  HIPCHK(hipMalloc(&t3, std::max<size_t>(w3.size(), 1) * sizeof(float)));
+  HIPCHK(hipMalloc(&t1, std::max<size_t>(w1.size(), 1) * sizeof(float)));
+  HIPCHK(hipMemcpy(t3, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t1, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t le = launch_pack_f16x3(t3, x.p, cout, cin3, 3, wscale, nullptr);
+  if (le == hipSuccess) le = launch_pack_f16x3(t1, reinterpret_cast<char*>(x.p) + h3 * 2, cout, cin1, 1, wscale, nullptr);
+  hipError_t se = hipDeviceSynchronize();
+  (void)hipFree(t3);
+  (void)hipFree(t1);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "f16x3 fused weight packing failed for " + name);
+  e->xw[key] = x;
+  return 0;
+}
+
 // conv weight [Cout][Cin][k][k] -> GEMM B operand [k*k][Cin][Cout]
 std::vector<float> pack_conv(const std::vector<float>& w, int cout, int cin, int k) {
   std::vector<float> o((size_t)k * k * cin * cout);
@@ -461,7 +499,8 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
-         const Act* resid, Act* out, bool want_stats = false, int rups = 0) {
+         const Act* resid, Act* out, bool want_stats = false, int rups = 0, const Act* sc0 = nullptr,
+         const Act* sc1 = nullptr, bool* fused = nullptr) {
   const int Hin = x0.H, Win = x0.W;
   int Ho = Hin, Wo = Win;
   if (ups) { Ho *= 2; Wo *= 2; }
@@ -487,6 +526,11 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
   g.ZI = 1; g.Z = c.B;
   g.math = MATH_F32;
+  if (sc0 && c.e->math != MATH_F16X3) {   // fused shortcut exists only in the f16x3 family
+    if (fused) *fused = false;
+    drop(c, *out);
+    return 0;
+  }
   if (c.e->math == MATH_F16X3) {
     auto it = c.e->xw.find(wname);
     if (it == c.e->xw.end()) return fail(ASYRP_EKEY, "missing f16x3 weight image " + wname);
@@ -494,6 +538,29 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     g.wpk = it->second.p;
     g.cout_pad = it->second.cout_pad;
     g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());   // both powers of two: exact
+    if (fused) *fused = false;
+    if (sc0) {   // try the fused 1x1 shortcut: needs the fused weight image and the main tile
+      auto fit = c.e->xw.find(wname + "#sc");
+      const float* fb = P(c, bname + "#sc");
+      if (fit != c.e->xw.end() && fb && !resid) {
+        GemmArgs t = g;
+        t.s0 = sc0->p; t.sc0 = sc0->C; t.lds0 = sc0->C; t.s0_zo = sc0->per_image();
+        if (sc1) { t.s1 = sc1->p; t.sc1 = sc1->C; t.lds1 = sc1->C; t.s1_zo = sc1->per_image(); }
+        t.Cin2 = sc0->C + (sc1 ? sc1->C : 0);
+        t.wpk = fit->second.p;
+        t.cout_pad = fit->second.cout_pad;
+        t.alpha = 1.0f / (fit->second.wscale * f16x3_act_scale());
+        t.bias = fb;
+        if (gemm_can_fuse_shortcut(t)) {
+          g = t;
+          *fused = true;
+        }
+      }
+      if (!(fused && *fused)) {   // not fusable here: nothing is launched, the caller runs the two-launch form
+        drop(c, *out);
+        return 0;
+      }
+    }
     if (want_stats) {   // the output will be group-normalised: its statistics come out of this launch's epilogue
       out->st_nblk = gemm_mblocks(g);
       float* sp = nullptr;
@@ -557,19 +624,23 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
            c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
   e->pool.put(sc1); e->pool.put(sh1);
   TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2));
-  Act sc;
-  bool own_sc = false;
   if (Cin != Cout) {
-    TRY(conv(c, x0, x1, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", Cout, 1, 1, 0, nullptr, nullptr, 0,
-             nullptr, nullptr, &sc));
-    own_sc = true;
+    // x + h with x = nin_shortcut(x): the 1x1 rides in conv2's K-loop when the launch runs on the fusing tile
+    bool fused = false;
+    TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, nullptr, out, true,
+             0, &x0, x1, &fused));
+    if (!fused) {
+      Act sc;
+      TRY(conv(c, x0, x1, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", Cout, 1, 1, 0, nullptr, nullptr, 0, nullptr,
+               nullptr, &sc));
+      TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sc, out, true));
+      drop(c, sc);
+    }
   } else {
-    sc = x0;   // identity shortcut never has a concat input
+    TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &x0, out, true));
   }
-  TRY(conv(c, h1, nullptr, p + ".conv2.weight", p + ".conv2.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sc, out, true));
   e->pool.put(sc2); e->pool.put(sh2);
   drop(c, h1);
-  if (own_sc) drop(c, sc);
   return 0;
 }
 
@@ -719,20 +790,25 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
   // h = GN(h) * (1 + scale) + shift, (scale, shift) = chunk(Linear(SiLU(emb)), 2)  (:290-294)
   const float* film = c.tproj + e->tproj_off.at(p);
   TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, e->tproj_total));
-  Act sk;
-  bool own_sk = false;
   if (Cin != Cout) {   // 1x1 skip_connection (never combined with up/down in the reference's arch dicts)
     if (L.mode) return fail(ASYRP_EINVAL, "resampling ResBlock with a channel change is not part of any reference config");
-    TRY(conv(c, x0, x1, p + ".skip_connection.weight", p + ".skip_connection.bias", Cout, 1, 1, 0, nullptr, nullptr, 0, nullptr,
-             nullptr, &sk));
-    own_sk = true;
-    skip_src = &sk;
+    bool fused = false;
+    TRY(conv(c, h1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, nullptr,
+             out, true, 0, &x0, x1, &fused));
+    if (!fused) {
+      Act sk;
+      TRY(conv(c, x0, x1, p + ".skip_connection.weight", p + ".skip_connection.bias", Cout, 1, 1, 0, nullptr, nullptr, 0,
+               nullptr, nullptr, &sk));
+      TRY(conv(c, h1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, &sk,
+               out, true));
+      drop(c, sk);
+    }
+  } else {
+    TRY(conv(c, h1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, skip_src,
+             out, true, rups));
   }
-  TRY(conv(c, h1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", Cout, 3, 1, 0, sc2, sh2, 1, nullptr, skip_src,
-           out, true, rups));
   e->pool.put(sc2); e->pool.put(sh2);
   drop(c, h1);
-  if (own_sk) drop(c, sk);
   if (own_xr) drop(c, xr);
   return 0;
 }
@@ -1152,6 +1228,21 @@ int asyrp_finalize_params(asyrp_engine* e) {
       } else {
         TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
         if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+        // a ResnetBlock / ResBlock with a 1x1 shortcut: fused image (second conv ++ shortcut) and fused bias
+        const char* c2 = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".out_layers.3" : ".conv2";
+        const char* sk = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".skip_connection" : ".nin_shortcut";
+        if (e->math == MATH_F16X3 && k == 3 && ends_with(p, c2)) {
+          const std::string blk = p.substr(0, p.size() - strlen(c2));
+          auto sit = e->spec_idx.find(blk + sk + ".weight");
+          if (sit != e->spec_idx.end()) {
+            const ParamSpec& ss = e->specs[sit->second];
+            TRY(pack_x3_fused(e, s.key, v, cout, cin, hostp(e, ss.key), (int)ss.shape[1]));
+            std::vector<float> fb = hostp(e, p + ".bias");
+            const auto& sb = hostp(e, blk + sk + ".bias");
+            for (size_t i = 0; i < fb.size(); ++i) fb[i] += sb[i];
+            TRY(upload(e, p + ".bias#sc", fb));
+          }
+        }
       }
     } else {
       const std::string p = s.key.substr(0, s.key.rfind('.'));
@@ -1478,6 +1569,77 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
   for (void* p : tmp) (void)hipFree(p);
   if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv+stats launch: ") + hipGetErrorString(le));
   if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv+stats sync: ") + hipGetErrorString(se));
+  return 0;
+}
+
+// y = conv3x3(swish(GroupNorm32(h))) + b3 + conv1x1(cat(x0, x1)) + b1 in ONE launch (fused shortcut on the main f16x3 tile):
+// the tail of a ResnetBlock with nin_shortcut (models/ddpm/diffusion.py:159-170)
+int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, int C0, const float* x1, int C1, int B, int H,
+                           int W, const float* w3, const float* b3, const float* w1, const float* b1, int Cout,
+                           const float* gn_weight, const float* gn_bias, float gn_eps, float* y, void* stream) {
+  if (!h || !x0 || !w3 || !w1 || !y || !gn_weight || !gn_bias || B < 1) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W, Cx = C0 + (x1 ? C1 : 0);
+  std::vector<void*> tmp;
+  auto dalloc = [&](size_t nfloats, float** p) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(nfloats, 1) * sizeof(float)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  float *hn, *a0, *a1 = nullptr, *yo, *xp, *sc, *sh, *part, *fb;
+  TRY(dalloc((size_t)B * HW * Ch, &hn));
+  HIPCHK(launch_nchw_to_nhwc(h, hn, B, Ch, HW, s));
+  TRY(dalloc((size_t)B * HW * C0, &a0));
+  HIPCHK(launch_nchw_to_nhwc(x0, a0, B, C0, HW, s));
+  if (x1) {
+    TRY(dalloc((size_t)B * HW * C1, &a1));
+    HIPCHK(launch_nchw_to_nhwc(x1, a1, B, C1, HW, s));
+  }
+  TRY(dalloc((size_t)B * HW * Cout, &yo));
+  TRY(dalloc((size_t)B * Ch, &sc));
+  TRY(dalloc((size_t)B * Ch, &sh));
+  TRY(dalloc(gn_partial_doubles(B, Ch, HW) * 2, &part));
+  GnArgs ga;
+  memset(&ga, 0, sizeof ga);
+  ga.a0 = hn; ga.c0 = Ch; ga.lda0 = Ch; ga.a0_z = (long long)HW * Ch; ga.HW = HW; ga.N = B; ga.C = Ch;
+  ga.gamma = gn_weight; ga.beta = gn_bias; ga.eps = gn_eps; ga.scale = sc; ga.shift = sh;
+  ga.partial = reinterpret_cast<double*>(part);
+  HIPCHK(launch_gn(ga, s));
+  std::vector<float> hw3((size_t)Cout * Ch * 9), hw1((size_t)Cout * Cx), hb3(Cout), hb1(Cout);
+  HIPCHK(hipMemcpy(hw3.data(), w3, hw3.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hw1.data(), w1, hw1.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hb3.data(), b3, Cout * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hb1.data(), b1, Cout * sizeof(float), hipMemcpyDeviceToHost));
+  float mx = 0.f;
+  for (float v : hw3) mx = std::max(mx, std::fabs(v));
+  for (float v : hw1) mx = std::max(mx, std::fabs(v));
+  const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx))) : 1.f;
+  const size_t h3 = f16x3_packed_halfs(Cout, Ch, 3), h1 = f16x3_packed_halfs(Cout, Cx, 1);
+  TRY(dalloc((h3 + h1 + 1) / 2, &xp));
+  HIPCHK(launch_pack_f16x3(w3, xp, Cout, Ch, 3, wscale, s));
+  HIPCHK(launch_pack_f16x3(w1, reinterpret_cast<char*>(xp) + h3 * 2, Cout, Cx, 1, wscale, s));
+  for (int i = 0; i < Cout; ++i) hb3[i] += hb1[i];
+  TRY(dalloc(Cout, &fb));
+  HIPCHK(hipMemcpyAsync(fb, hb3.data(), Cout * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = hn; g.c0 = Ch; g.lda0 = Ch; g.a0_zo = (long long)HW * Ch;
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.Cin = Ch; g.Cout = Cout;
+  g.ks = 3; g.stride = 1; g.pad = 1; g.pscale = sc; g.pshift = sh; g.silu = 1;
+  g.bias = fb; g.out = yo; g.ldo = Cout; g.o_zo = (long long)HW * Cout; g.ZI = 1; g.Z = B;
+  g.math = MATH_F16X3; g.tile = XT_256x128; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
+  g.alpha = 1.0f / (wscale * f16x3_act_scale());
+  g.s0 = a0; g.sc0 = C0; g.lds0 = C0; g.s0_zo = (long long)HW * C0;
+  if (x1) { g.s1 = a1; g.sc1 = C1; g.lds1 = C1; g.s1_zo = (long long)HW * C1; }
+  g.Cin2 = Cx;
+  hipError_t le = gemm_can_fuse_shortcut(g) ? launch_gemm(g, s) : hipErrorInvalidValue;
+  if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, HW, s);
+  hipError_t se = hipStreamSynchronize(s);
+  for (void* p : tmp) (void)hipFree(p);
+  if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("fused resblock tail launch: ") + hipGetErrorString(le));
+  if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("fused resblock tail sync: ") + hipGetErrorString(se));
   return 0;
 }
 

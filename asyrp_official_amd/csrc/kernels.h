@@ -33,6 +33,10 @@ struct GemmArgs {
   // 1/(weight scale * f16x3_act_scale())
   int math;                       // MATH_F32 (v_mfma_f32_32x32x2_f32) or MATH_F16X3 (3 x v_mfma_f32_32x32x16_f16)
   const void* wpk; int cout_pad;
+  // fused 1x1 shortcut (f16x3 main tile only): after the Cin/16 chunks x 9 taps of the 3x3 conv the K-loop runs Cin2/16 more
+  // single-tap chunks over the raw (no prologue) virtual concat (s0|s1) with the 1x1 weights appended to `wpk`
+  // (ResnetBlock.nin_shortcut, models/ddpm/diffusion.py:145-149,165-170; ResBlock.skip_connection, improved_ddpm/unet.py:264,298)
+  const float* s0; const float* s1; int sc0, sc1, lds0, lds1; long long s0_zo, s1_zo; int Cin2;
   double* stats;                  // f16x3 only, nullable: per-(image, M-block, out channel) {sum, sumsq} of the output,
                                   //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
   int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
@@ -74,6 +78,7 @@ struct GnArgs {
 size_t gn_partial_doubles(int N, int C, int HW);
 hipError_t launch_gn(const GnArgs& a, hipStream_t s);
 int gn_nblk_of(int HW);                       // M-blocks launch_gn_partial writes
+bool gemm_can_fuse_shortcut(const GemmArgs& a);   // true when launch_gemm_f16x3 would run `a` (with s0/Cin2 set) on the fusing tile
 int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats
 // standalone partial statistics of one NHWC tensor -> partial [N][gn_nblk_of(HW)][C][2] doubles
 hipError_t launch_gn_partial(const float* a, int lda, long long a_z, int HW, int N, int C, double* partial, hipStream_t s);

@@ -413,9 +413,10 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
 
 void gemm_work(const GemmArgs& a, double* flops, double* bytes) {
   const double M = (double)a.Hout * a.Wout * a.Z;
-  const double K = (double)a.ks * a.ks * a.Cin;
+  const double K = (double)a.ks * a.ks * a.Cin + (a.s0 ? (double)a.Cin2 : 0.0);   // + fused 1x1 shortcut
   *flops = 2.0 * M * a.Cout * K;
-  const double in_elems = (double)a.Hin * a.Win * a.Cin * a.Z;
+  double in_elems = (double)a.Hin * a.Win * a.Cin * a.Z;
+  if (a.s0) in_elems += M * a.Cin2;
   const double w_elems = (a.w_zo || a.w_zi) ? K * a.Cout * a.Z : K * a.Cout;
   double out_elems = M * a.Cout;
   if (a.resid) out_elems += M * a.Cout;

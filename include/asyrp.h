@@ -183,6 +183,12 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
 int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int W, const float* weight,
                           const float* bias, int Cout, int ksize, int tile, const float* gamma, const float* beta,
                           float eps, float* y, float* scale_out, float* shift_out, void* stream);
+/* The tail of a ResnetBlock with a 1x1 shortcut as ONE launch (fused shortcut of the main f16x3 tile):
+ *   y = conv3x3(swish(GroupNorm32(h; gn_weight, gn_bias, eps)), w3) + b3 + conv1x1(cat(x0, x1), w1) + b1
+ * (models/ddpm/diffusion.py:159-170).  h [B,Ch,H,W], x0 [B,C0,H,W], x1 [B,C1,H,W] or null; channel counts multiples of 16. */
+int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, int C0, const float* x1, int C1, int B, int H,
+                           int W, const float* w3, const float* b3, const float* w1, const float* b1, int Cout,
+                           const float* gn_weight, const float* gn_bias, float gn_eps, float* y, void* stream);
 /* Kernel micro-benchmark (scripts/conv_bench.py): times `iters` launches of one conv configuration on synthetic
  * NHWC buffers with HIP events and returns the average in *ms_out (host pointer).  `abl` != 0 selects the profiling
  * build of the main f16x3 tile with phases switched off (timing ablations only). */

@@ -136,6 +136,34 @@ def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,Ch,C0,C1,Cout,H,W", [(1, 64, 64, 32, 64, 16, 16), (2, 128, 128, 128, 128, 40, 24),
+                                                   (1, 32, 48, 0, 160, 20, 36)])
+def test_fused_shortcut_resblock_tail(B, Ch, C0, C1, Cout, H, W):
+    """conv3x3(swish(GN(h))) + nin_shortcut(cat(x0, x1)) in one launch: the shortcut's 1x1 runs as extra single-tap K-chunks
+    of the 3x3 conv (partial tiles, two-source concat, Cout not a multiple of the N tile)."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    tag = f"sc.{Ch}.{C0}.{C1}.{Cout}"
+    h = hash_normal(tag + ".h", (B, Ch, H, W)) * 2.0 + 0.3
+    x0 = hash_normal(tag + ".x0", (B, C0, H, W))
+    x1 = hash_normal(tag + ".x1", (B, C1, H, W)) * 1.5 if C1 else None
+    w3 = hash_uniform(tag + ".w3", (Cout, Ch, 3, 3), -1, 1) / (Ch * 9) ** 0.5
+    w1 = hash_uniform(tag + ".w1", (Cout, C0 + C1, 1, 1), -1, 1) / (C0 + C1) ** 0.5
+    b3, b1 = 0.1 * hash_uniform(tag + ".b3", (Cout,)), 0.1 * hash_uniform(tag + ".b1", (Cout,))
+    gw, gb = 1 + 0.1 * hash_uniform(tag + ".g", (Ch,)), 0.1 * hash_uniform(tag + ".be", (Ch,))
+    d = lambda t: None if t is None else t.cuda().contiguous()
+    hd, x0d, x1d, w3d, w1d, b3d, b1d, gwd, gbd = map(d, (h, x0, x1, w3, w1, b3, b1, gw, gb))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    _lib.check(lib.asyrp_op_resblock_tail(0, _p(hd), Ch, _p(x0d), C0, _p(x1d), C1, B, H, W, _p(w3d), _p(b3d), _p(w1d), _p(b1d),
+                                          Cout, _p(gwd), _p(gbd), 1e-6, _p(y), None))
+    torch.cuda.synchronize()
+    a = F.group_norm(h, 32, gw, gb, eps=1e-6)
+    a = a * torch.sigmoid(a)
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    want = F.conv2d(a, w3, b3, padding=1) + F.conv2d(x, w1, b1)
+    assert_close(y.cpu(), want, what="fused shortcut", **TIGHT)
+
+
 @pytest.mark.parametrize("mag", [1.0, 1e-2, 1e-4, 1e-6])
 def test_f16x3_small_magnitude_operands_keep_subnormal_lo_terms(mag):
     """x = x_hi + x_lo with f16 terms has relative precision 2^-22 while x_lo is a normal f16 (|x| >= 0.125) and an ABSOLUTE
