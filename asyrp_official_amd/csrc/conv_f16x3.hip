@@ -116,7 +116,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int zo = blockIdx.z;
-  const int n0 = blockIdx.y * BN;
+  const int sk = (PIPE && p.sk > 1) ? p.sk : 1;          // split-K: blockIdx.y = n_block * sk + k_range
+  const int ks_id = blockIdx.y % sk;
+  const int n0 = (blockIdx.y / sk) * BN;
   const int HWo = p.Hout * p.Wout;
   int m0 = 0, oy0 = 0, ox0 = 0;
   if (KS == 1) {
@@ -292,8 +294,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  const int nchunks = nch1 + (SC ? p.Cin2 / XKC : 0);
-  const int nsteps = nch1 * NTAPS + (SC ? p.Cin2 / XKC : 0);
+  const int cb = ks_id * (nch1 / sk);                     // first chunk of this workgroup's K range (0 without split-K)
+  const int nchunks = (sk > 1) ? cb + nch1 / sk : nch1 + (SC ? p.Cin2 / XKC : 0);   // one past the last chunk
+  const int nsteps = (sk > 1) ? (nch1 / sk) * NTAPS : nch1 * NTAPS + (SC ? p.Cin2 / XKC : 0);
 
   if (PIPE) {
     constexpr int RB = T::RB, NPW = T::NPW, TS = T::TS;
@@ -314,27 +317,28 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     };
-    const int nfat = nsteps / TS;
-    // ---- prologue: chunk 0 + weight slot 0 staged, slots 1..RB-1 in flight, fragments of step 0 in registers ----
-    issue_slot(0, 0);
-    gload_A(0);
-    write_A(0, 0);
+    const int fs0 = cb * (NTAPS / TS);          // absolute index of this workgroup's first fat slice
+    const int nfat = fs0 + nsteps / TS;          // one past its last
+    // ---- prologue: first chunk + weight slot 0 staged, slots 1..RB-1 in flight, fragments of step 0 in registers ----
+    issue_slot(fs0, 0);
+    gload_A(cb);
+    write_A(cb, cb & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int j = 1; j < RB; ++j)
-      if (j < nfat) issue_slot(j, j);
-    if (NTAPS == 1 && nchunks > 1) gload_A(1);   // 1x1: chunk 1 is written during step 0
+      if (fs0 + j < nfat) issue_slot(fs0 + j, j);
+    if (NTAPS == 1 && cb + 1 < nchunks) gload_A(cb + 1);   // 1x1: the second chunk is written during step 0
     h8 ah[TM], al[TM], bh[TN], bl[TN];
     {
-      const char* A = As + kh * NPIX * 16;
+      const char* A = As + (cb & 1) * A_BYTES + kh * NPIX * 16;
       const char* B = Bs + boff;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
     }
-    int chunk = 0, tap = 0, slot = 0, tt = 0, fs = 0;   // slot = fs % RB, tt = step % TS
+    int chunk = cb, tap = 0, slot = 0, tt = 0, fs = fs0;   // slot = (fs - fs0) % RB, tt = step % TS
     for (int step = 0; step < nsteps; ++step) {
       const int ntaps_c = (SC && chunk >= nch1) ? 1 : NTAPS;   // shortcut chunks have the centre tap only
       const bool last_tap = (tap == ntaps_c - 1);
@@ -527,6 +531,32 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       d[1] = s2;
     }
   };
+  if (sk > 1) {   // split-K: raw partial sums; bias / residual / statistics belong to launch_splitk_reduce
+    float* __restrict__ part = p.part + ((size_t)(ks_id * (int)gridDim.z + zo) * HWo) * Cout;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          int pixel;
+          bool ok;
+          if (KS == 1) {
+            pixel = m0 + m;
+            ok = pixel < HWo;
+          } else {
+            const int oy = oy0 + m / PW, ox = ox0 + (m % PW);
+            ok = (oy < p.Hout) && (ox < p.Wout);
+            pixel = oy * p.Wout + ox;
+          }
+          if (ok && n < Cout) part[pixel * Cout + n] = acc[tm][tn][r] * p.alpha;
+        }
+      }
+    }
+    return;
+  }
   if (full) {
     // interior tile: no bounds checks
 #pragma unroll
@@ -639,7 +669,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   } else {
     gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
   }
-  const int gy = (a.Cout + T::BN - 1) / T::BN;
+  int gy = (a.Cout + T::BN - 1) / T::BN;
+  if (a.sk > 1) {
+    const int nch = (a.Cin + XKC - 1) / XKC;
+    if (!PIPE || SC || !a.part || a.s0 || nch % a.sk != 0 || (a.Cin % XKC) != 0) return hipErrorInvalidValue;
+    gy *= a.sk;
+  }
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
@@ -775,6 +810,55 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     }
   }
   return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// split-K reduction: out = sum_ks part[ks] (fixed order) + bias + chan_add + resid, plus the GroupNorm partials of `out`
+// one workgroup per (pixel block, image); a thread owns channels c, c + 256, ... and walks the block's pixels
+// ---------------------------------------------------------------------------------------------------
+static bool is_vec(const GemmArgs& a);
+constexpr int SKR_PIX = 8;    // pixels per reduce workgroup == pixels per statistics row (8x8 image -> 8 workgroups per image)
+
+int splitk_stat_blocks(int HW) { return (HW + SKR_PIX - 1) / SKR_PIX; }
+
+int splitk_factor(const GemmArgs& a) {
+  if (a.math != MATH_F16X3 || !a.wpk || a.ks != 3 || a.stride != 1 || a.ups || a.s0 || a.rups || a.abl) return 1;
+  // measured (profiles/r01_conv_microbench_kb8_splitk.txt, B=32): 1024->512 @8x8 179 -> 134 us; 512->512 @8x8 no gain (91 us
+  // either way: with 32 chunks a workgroup's fixed prologue/epilogue latency equals its share of the loop)
+  if (a.Hout * a.Wout > 64 || a.Cin < 1024 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
+  return 8;
+}
+
+__global__ void splitk_reduce_kernel(const GemmArgs p, int HW) {
+  const int blk = blockIdx.x, zo = blockIdx.y, Z = gridDim.y, Cout = p.Cout;
+  const int p0 = blk * SKR_PIX, p1 = min(HW, p0 + SKR_PIX);
+  const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
+  const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+  for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+    const float add = (p.bias ? p.bias[c] : 0.f) + (cadd ? cadd[c] : 0.f);
+    double s1 = 0.0, s2 = 0.0;
+    for (int pix = p0; pix < p1; ++pix) {
+      float v = 0.f;
+      for (int k = 0; k < p.sk; ++k) v += p.part[(((size_t)k * Z + zo) * HW + pix) * Cout + c];
+      v = (v + add) + (rz ? rz[(size_t)pix * p.ldr + c] : 0.f);
+      outz[(size_t)pix * p.ldo + c] = v;
+      s1 += (double)v;
+      s2 += (double)v * (double)v;
+    }
+    if (p.stats) {
+      double* dst = p.stats + (((size_t)zo * gridDim.x + blk) * Cout + c) * 2;
+      dst[0] = s1;
+      dst[1] = s2;
+    }
+  }
+}
+
+hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
+  if (a.sk < 2 || !a.part || a.rups) return hipErrorInvalidValue;
+  const int HW = a.Hout * a.Wout;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_stat_blocks(HW), a.Z), dim3(256), 0, s, a, HW);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -561,12 +561,27 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
         return 0;
       }
     }
+    // 8x8 layers: M x N has fewer tiles than the chip has CUs and K is thousands deep -> split K over 8 workgroups per
+    // tile and reduce in a second, tiny launch.  The decision depends on the layer shape only (never on the batch), so
+    // an image's result does not depend on what it is batched with.
+    const int sk = splitk_factor(g);
+    if (sk > 1) {
+      g.sk = sk;
+      g.tile = XT_64x64;
+      TRY(c.e->pool.get((size_t)sk * c.B * Ho * Wo * Cout, &g.part));
+    }
     if (want_stats) {   // the output will be group-normalised: its statistics come out of this launch's epilogue
-      out->st_nblk = gemm_mblocks(g);
+      out->st_nblk = (sk > 1) ? splitk_stat_blocks(Ho * Wo) : gemm_mblocks(g);
       float* sp = nullptr;
       TRY(c.e->pool.get((size_t)c.B * out->st_nblk * Cout * 4, &sp));
       out->st = reinterpret_cast<double*>(sp);
       g.stats = out->st;
+    }
+    if (sk > 1) {
+      TRY(run_gemm(c, g));
+      HIPCHK(launch_splitk_reduce(g, c.s));
+      c.e->pool.put(g.part);
+      return 0;
     }
   }
   return run_gemm(c, g);
@@ -1702,13 +1717,24 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
     g.math = MATH_F16X3; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
     g.alpha = 1.0f / (wscale * f16x3_act_scale());
   }
+  const int sk = (tile == 0) ? splitk_factor(g) : 1;   // as the engine does when it picks the tile itself
+  if (sk > 1) {
+    g.sk = sk;
+    g.tile = XT_64x64;
+    TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part, 0.f, 11));
+  }
+  auto once = [&]() -> hipError_t {
+    hipError_t e = launch_gemm(g, s);
+    if (e == hipSuccess && sk > 1) e = launch_splitk_reduce(g, s);
+    return e;
+  };
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   hipError_t le = hipSuccess;
-  for (int i = 0; i < 2 && le == hipSuccess; ++i) le = launch_gemm(g, s);
+  for (int i = 0; i < 2 && le == hipSuccess; ++i) le = once();
   (void)hipEventRecord(e0, s);
-  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_gemm(g, s);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = once();
   (void)hipEventRecord(e1, s);
   hipError_t se = hipStreamSynchronize(s);
   float ms = 0.f;

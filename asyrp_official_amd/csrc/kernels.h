@@ -37,6 +37,11 @@ struct GemmArgs {
   // single-tap chunks over the raw (no prologue) virtual concat (s0|s1) with the 1x1 weights appended to `wpk`
   // (ResnetBlock.nin_shortcut, models/ddpm/diffusion.py:145-149,165-170; ResBlock.skip_connection, improved_ddpm/unet.py:264,298)
   const float* s0; const float* s1; int sc0, sc1, lds0, lds1; long long s0_zo, s1_zo; int Cin2;
+  // split-K (f16x3 pipelined tiles): sk > 1 splits the Cin/16 chunks into sk equal ranges, one workgroup each
+  // (gridDim.y = n_blocks * sk); every range writes alpha * acc to part[ks][z][pixel][Cout] and launch_splitk_reduce adds
+  // them in a fixed order together with bias / chan_add / residual (and emits the GroupNorm partials).  Used for the 8x8
+  // layers, whose M x N offers fewer tiles than the chip has CUs.
+  int sk; float* part;
   double* stats;                  // f16x3 only, nullable: per-(image, M-block, out channel) {sum, sumsq} of the output,
                                   //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
   int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
@@ -78,6 +83,10 @@ struct GnArgs {
 size_t gn_partial_doubles(int N, int C, int HW);
 hipError_t launch_gn(const GnArgs& a, hipStream_t s);
 int gn_nblk_of(int HW);                       // M-blocks launch_gn_partial writes
+// out = sum_ks part[ks] + bias + chan_add + resid; stats (nullable) = [Z][splitk_stat_blocks(HW)][Cout][2] doubles
+hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
+int splitk_stat_blocks(int HW);
+int splitk_factor(const GemmArgs& a);   // 1 = none; a function of the LAYER SHAPE only (batch-invariant results)
 bool gemm_can_fuse_shortcut(const GemmArgs& a);   // true when launch_gemm_f16x3 would run `a` (with s0/Cin2 set) on the fusing tile
 int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats
 // standalone partial statistics of one NHWC tensor -> partial [N][gn_nblk_of(HW)][C][2] doubles

@@ -52,6 +52,12 @@ if __name__ == "__main__":
         for math in ("f16x3",):
             ms, tf = run(H, C0, C1, Co, k, math=math, **kw)
             print(f"{name:40s} {math:6s} {ms:8.3f} ms {tf:7.1f} TFLOP/s", flush=True)
+    print("-- 8x8 layers: engine choice (split-K 8 + reduce) vs single-pass 64x64 tile")
+    for (Ch, C1) in ((512, 0), (512, 512)):
+        for rnd in range(3):
+            a = run(8, Ch, C1, 512, 3, tile=0, iters=10)
+            b_ = run(8, Ch, C1, 512, 3, tile=4, iters=10)
+            print(f"  {Ch}+{C1}->512 @8 r{rnd}: split-K {a[0]*1e3:7.1f} us {a[1]:6.1f} TF   single {b_[0]*1e3:7.1f} us {b_[1]:6.1f} TF", flush=True)
     print("-- A/B interleaved: weight-slice ring of 3 (tile 1) vs 2 (tile 7) vs 4 (tile 8), 4 rounds")
     for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
         for rnd in range(4):
