@@ -109,8 +109,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   constexpr bool LOWREG = (NW >= 8);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;
-  char* const Bs = smem + 2 * A_BYTES;
+  // weight ring first: LDS-DMA destinations go through M0, kept below 64 KB; the halo tiles behind it are written by ds_write
+  char* const Bs = smem;
+  char* const As = smem + T::RB * T::TS * B_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     static_assert((TS * T::NPIECE) % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slot (counted vmcnt)");
     static_assert(NTAPS % TS == 0, "a fat step must not straddle two channel chunks");
     static_assert(!SC || TS == 1, "the fused shortcut's single-tap chunks need single-tap steps");
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)Bs);
     // one ring slot = TS consecutive tap slices (they are consecutive in the packed weight image)
     auto issue_slot = [&](int fs, int slot) {
 #pragma unroll
@@ -312,9 +314,14 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         const int tt = pc / NPIECE, q = pc - tt * NPIECE;
         const int u = q / (BN / 64), part = q - u * (BN / 64);
         const char* src = wpk + ((long long)((fs * TS + tt) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
-        char* dst = Bs + slot * SLOT_BYTES + tt * B_BYTES + (u * BN + part * 64) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        const unsigned dst = lds_base + slot * SLOT_BYTES + tt * B_BYTES + (u * BN + part * 64) * 16;
+        // inline asm: hipcc drains vmcnt(0) before every LDS-DMA it can see behind another one still in flight, which would
+        // undo the counted waits below; M0 (the LDS destination base) is saved/restored inside the statement
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                     : "memory");
       }
     };
     const int fs0 = cb * (NTAPS / TS);          // absolute index of this workgroup's first fat slice
@@ -749,8 +756,8 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   const int tile = eff_tile_x(a);
   // last parameter: weight-slice ring size of the pipelined loop (slices stay in flight for RB-1 K-steps); the small
   // tiles have short K-steps (3-6 MFMAs per wave), so they need the deeper ring to cover the L2 latency of a slice
-  using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1, 3>;
-  using X256x128_3r2 = XCfg<4, 1, 2, 4, 3, 1, 2>;
+  using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1, 2>;      // ring of 2: deeper rings measured equal (3) or slower (4) on this tile
+  using X256x128_3r2 = XCfg<4, 1, 2, 4, 3, 1, 3>;
   using X256x128_3r4 = XCfg<4, 1, 2, 4, 3, 1, 4>;
   using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1, 2, 3>;    // 11.5 KB x 2 halo + 2 x 24 KB weight slots = 71 KB: 2 workgroups per CU
   using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1, 2, 3>;     // 61 KB
@@ -761,7 +768,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
-  using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 3>;
+  using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 2>;
   using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1, 4>;
   using X64x128_1 = XCfg<2, 2, 1, 2, 1, 1, 4>;
   using X64x64_1 = XCfg<2, 2, 1, 1, 1, 1, 4>;
@@ -794,7 +801,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 2
+      case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 3
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
       case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);
       case 10: return launch_x<X64x128_3t1, true, false, true>(a, s);
