@@ -263,7 +263,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     for (int pc0 = 0; pc0 < NPIECE; pc0 += NW) {
       const int pc = pc0 + wave;
       if (pc < NPIECE) {
-        const int u = pc / (BN / 64), part = pc - u * (BN / 64);
+        constexpr int PPU = (BN >= 64) ? BN / 64 : 1;   // (the un-pipelined loop is not instantiated for BN = 32)
+        const int u = pc / PPU, part = pc - u * PPU;
         const char* src = wpk + ((long long)(step * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
         char* dst = Bs + buf * B_BYTES + (u * BN + part * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -302,7 +303,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   if (PIPE) {
     constexpr int RB = T::RB, NPW = T::NPW, TS = T::TS;
     constexpr int SLOT_BYTES = TS * B_BYTES;
-    static_assert((TS * T::NPIECE) % NW == 0, "every wave must issue the same number of LDS-DMA pieces per slot (counted vmcnt)");
+    static_assert((TS * T::NPIECE) % NW == 0 || RB == 2,
+                  "a ring deeper than 2 counts LDS-DMA instructions per wave: every wave must issue the same number per slot");
     static_assert(NTAPS % TS == 0, "a fat step must not straddle two channel chunks");
     static_assert(!SC || TS == 1, "the fused shortcut's single-tap chunks need single-tap steps");
     const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)Bs);
@@ -311,10 +313,15 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
       for (int pc0 = 0; pc0 < TS * NPIECE; pc0 += NW) {
         const int pc = pc0 + wave;
+        if ((TS * NPIECE) % NW != 0 && pc >= TS * NPIECE) break;   // wave-uniform
         const int tt = pc / NPIECE, q = pc - tt * NPIECE;
-        const int u = q / (BN / 64), part = q - u * (BN / 64);
-        const char* src = wpk + ((long long)((fs * TS + tt) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
-        const unsigned dst = lds_base + slot * SLOT_BYTES + tt * B_BYTES + (u * BN + part * 64) * 16;
+        int u, part, nl;
+        constexpr int PPU = (BN >= 64) ? BN / 64 : 1;
+        if (BN >= 64) { u = q / PPU; part = q - u * PPU; nl = part * 64 + lane; }
+        else { u = q * 2 + (lane >> 5); part = 0; nl = lane & 31; }   // BN = 32: one 1-KiB piece carries two units
+        const char* src = wpk + ((long long)((fs * TS + tt) * 4 + u) * p.cout_pad + n0 + nl) * 16;
+        const unsigned dst = lds_base + slot * SLOT_BYTES + tt * B_BYTES +
+                             ((BN >= 64) ? (u * BN + part * 64) * 16 : q * 1024);
         // inline asm: hipcc drains vmcnt(0) before every LDS-DMA it can see behind another one still in flight, which would
         // undo the counted waits below; M0 (the LDS destination base) is saved/restored inside the statement
         unsigned keep;
@@ -708,6 +715,7 @@ static int auto_tile_x(const GemmArgs& a) {
     }
     return mt * ((a.Cout + bn - 1) / bn) * a.Z;
   };
+  if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
   if (M >= 256 && blocks(256, 128) >= 512) return XT_256x128;
   // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
@@ -727,7 +735,8 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4 ||
+          t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -740,7 +749,8 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: bm = 256; break;
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: case XT_256x32:
+      bm = 256; break;
     case XT_128x128: case 9: bm = 128; break;
     default: bm = 64;
   }
@@ -767,6 +777,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X64x64_3t1 = XCfg<2, 2, 1, 1, 3, 1, 4>;
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
+  using X256x32_3 = XCfg<4, 1, 2, 1, 3, 1, 2, 1>;     // conv_out (Cout = 3 / 6): 32-wide N tile, 6 MFMAs per wave per K-step
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
   using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 2>;
   using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1, 4>;
@@ -800,6 +811,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_64x128: return launch_x<X64x128_3, true, false, true>(a, s);
       case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
+      case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
       case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 3
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4

@@ -78,6 +78,16 @@ def test_conv3x3_plain(B, Cin, Cout, H, math):
     assert_close(hip_conv(x, w, b, math=math), ref_conv(x, w, b), what="conv3x3", **TIGHT)
 
 
+def test_f16x3_narrow_tile_for_conv_out():
+    """256x32 tile (conv_out: 128 -> 3 / 6 channels at full resolution): forced and as the launcher's own choice."""
+    for Cout, tile in ((3, 12), (6, 12), (6, 0)):
+        B, Cin, H = 2, 32, 48
+        x, w, b = _mk(B, Cin, Cout, H, 3, f"narrow.{Cout}")
+        gn = (1 + 0.1 * hash_uniform("narrow.g", (Cin,)), 0.1 * hash_uniform("narrow.be", (Cin,)))
+        got = hip_conv(x, w, b, gn=gn, silu=True, tile=tile)
+        assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out tile {tile} Cout {Cout}", **TIGHT)
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
