@@ -51,6 +51,7 @@ enum { MATH_F16X3 = 0, MATH_F32 = 1 };
 
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 
+// ids 7..11 are A/B variants kept for scripts/conv_bench.py (ring depth 3 / 4 on the main tile; single-tap steps on the small tiles)
 enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
        XT_256x128_PLAIN = 7 /* A/B: weight ring of 3 */, XT_256x128_R4 = 8 /* A/B: weight ring of 4 */,
        XT_256x32 = 12 /* conv_out: Cout <= 32 */ };
