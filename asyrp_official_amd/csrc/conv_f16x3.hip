@@ -97,9 +97,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
 // SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (PIPE, TS=1)
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
+// SPRIO: static asymmetric priority: the wave in the odd hardware wave slot of each SIMD runs at priority 2 for its whole
+//       life, so the two co-resident workgroups of a CU do not convoy on the matrix pipe (A/B experiment)
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
+  if (SPRIO) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (hwid & 1) __builtin_amdgcn_s_setprio(2);
+  }
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, PW = T::PW, TW = T::TW;
   constexpr int NPIX = T::NPIX, A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, NA = T::NA, NTAPS = T::NTAPS;
@@ -675,7 +682,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -692,12 +699,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -813,7 +820,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128_PLAIN: return launch_x<X256x128_3r2, true, false, true>(a, s);   // A/B: ring of 3
+      case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, false, true>(a, s);   // A/B: static priority
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
       case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);
       case 10: return launch_x<X64x128_3t1, true, false, true>(a, s);
