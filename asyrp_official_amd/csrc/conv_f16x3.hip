@@ -677,300 +677,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   }
 }
 
-// =====================================================================================================================
-// igemm_f16x3_duo: the 3x3 / stride-1 conv as ONE 8-wave workgroup per CU whose two 4-wave groups ALTERNATE roles under a
-// common barrier: in every phase one group issues its 24 MFMAs of a K-step from register-resident fragments (one wave per
-// SIMD, alone on the matrix pipe), while the other group does everything else for ITS next K-step -- fragment reads, the
-// weight LDS-DMA, activation loads and the GroupNorm/SiLU/split staging pass.  The 4-wave kernel above runs two independent
-// workgroups per CU instead; its waves convoy on the matrix pipe and wait on each other's barriers (SQ_WAIT_ANY 38 %,
-// MFMA utilisation 47-54 %, profiles/r01_pmc_main_tile/).  Tile: 32 x 16 output pixels x 128 channels, group g = rows 8g..8g+7.
-//   phase 2s   : group 0 MFMA(step s)        | group 1 SERVICE(step s)     (reads fragments of step s, stages, ...)
-//   phase 2s+1 : group 1 MFMA(step s)        | group 0 SERVICE(step s+1)   (+ issues the weight slice of step s+2)
-// Same products in the same order over K as every other variant.
-// =====================================================================================================================
-struct DuoCfg {
-  static constexpr int NW = 8, NT = 512, TM = 2, TN = 4, BM = 512, BN = 128, PW = 32, PH = 16, KS = 3;
-  static constexpr int TW = PW + 2, TH = PH + 2, NPIX = TW * TH;          // 34 x 18 halo
-  static constexpr int A_BYTES = NPIX * 64, B_BYTES = BN * 64;
-  static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;            // 1224 work items, 3 per thread
-  static constexpr int MAX_CIN = 2048;                                    // GroupNorm scale+shift of one image live in LDS
-  static constexpr size_t SMEM = 2 * (size_t)B_BYTES + 2 * (size_t)A_BYTES + 2 * MAX_CIN * sizeof(float);
-};
-
-__global__ void __launch_bounds__(512, 2) igemm_f16x3_duo_kernel(const GemmArgs p) {
-  using T = DuoCfg;
-  constexpr int TM = T::TM, TN = T::TN, NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, NPIX = T::NPIX;
-  constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, NA = T::NA, NU = T::NU, NTAPS = 9;
-  static_assert(NA == 3, "the staging schedule below spreads exactly three work items per thread over a chunk's nine taps");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Bs = smem;                       // 2 weight slots (LDS-DMA destinations: below 64 KB)
-  char* const As = smem + 2 * B_BYTES;         // 2 halo tiles
-  float* const Ss = reinterpret_cast<float*>(smem + 2 * B_BYTES + 2 * A_BYTES);   // [scale Cin | shift Cin] of this image
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave >> 2;                     // group: 0 computes on even phases, 1 on odd phases
-  const int zo = blockIdx.z, n0 = blockIdx.y * BN;
-  const int tiles_x = (p.Wout + PW - 1) / PW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * T::PH, ox0 = tx * PW;
-  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
-  const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo : nullptr;
-  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
-  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
-  const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
-  const int Cout = p.Cout, c0 = p.c0;
-  const int nchunks = p.Cin / XKC, nsteps = nchunks * NTAPS;
-
-  // ---- staging map: work item u = (halo pixel, 8-channel half); the source pixel is recomputed per use (registers) ----
-  const int hf = tid & 1;
-  auto src_pixel = [&](int i) -> int {   // >= 0 source pixel, -1 zero padding, -2 no work item
-    const int u = tid + i * NT, pix = u >> 1;
-    if (u >= NU) return -2;
-    const int iy = pix / TW, ix = pix - iy * TW;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-    const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
-    return (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
-  };
-  float4 areg[2];     // ONE work item in flight (loaded at tap 0/3/6, written at tap 2/5/8)
-
-  // exactly two global_load_dwordx4 per wave and call, whatever the lanes' pixels are (padding / idle lanes read pixel 0
-  // and discard it): the counted vmcnt of the MFMA phase relies on the instruction count
-  auto load_item = [&](int chunk, int i) {
-    const int c = chunk * XKC + hf * 8;
-    const bool second = (chunk * XKC >= c0);
-    const float* __restrict__ base = second ? a1 + (c - c0) : a0 + c;
-    const int ld = second ? p.lda1 : p.lda0;
-    const int so = src_pixel(i);
-    const int sp = so >= 0 ? so : 0;
-    const float* src = base + (long long)sp * ld;
-    areg[0] = *reinterpret_cast<const float4*>(src);
-    areg[1] = *reinterpret_cast<const float4*>(src + 4);
-  };
-  auto write_item = [&](int chunk, int i) {
-    const int so = src_pixel(i);
-    if (so == -2) return;
-    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (so >= 0) {
-      t[0] = areg[0].x; t[1] = areg[0].y; t[2] = areg[0].z; t[3] = areg[0].w;
-      t[4] = areg[1].x; t[5] = areg[1].y; t[6] = areg[1].z; t[7] = areg[1].w;
-      if (ps) {   // GroupNorm scale / shift of this thread's 8 channels, from the LDS copy made in the prologue
-        const int c = chunk * XKC + hf * 8;
-        const float4 s0 = *reinterpret_cast<const float4*>(Ss + c), s1 = *reinterpret_cast<const float4*>(Ss + c + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(Ss + p.Cin + c), h1 = *reinterpret_cast<const float4*>(Ss + p.Cin + c + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = __builtin_fmaf(t[j], sc[j], sh[j]);
-      }
-      if (p.silu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = silu_fast(t[j]);
-      }
-    }
-    h8 hi, lo;
-    split8(t, hi, lo);
-    const int pix = (tid + i * NT) >> 1;
-    char* dst = As + (chunk & 1) * A_BYTES + (hf * NPIX + pix) * 16;
-    *reinterpret_cast<h8*>(dst) = hi;
-    *reinterpret_cast<h8*>(dst + 2 * NPIX * 16) = lo;
-  };
-  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)Bs);
-  // a weight slice = 8 one-KiB pieces; `nw` waves share them (8 in the prologue, the 4 of group 0 in the loop)
-  auto issue_B = [&](int step, int slot, int w, int nw) {
-    for (int pc = w; pc < 8; pc += nw) {
-      const int u = pc >> 1, part = pc & 1;
-      const char* src = wpk + ((long long)(step * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
-      const unsigned dst = lds_base + slot * B_BYTES + (u * BN + part * 64) * 16;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
-                   : "memory");
-    }
-  };
-
-  // ---- MFMA operand addressing: wave `wave` owns output rows 2*wave, 2*wave+1 of the 32x16 patch ----
-  const int kh = lane >> 5;
-  int apix[TM];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) apix[tm] = (wave * TM + tm) * TW + (lane & 31);   // tile pixel of output (row, col=lane&31), tap (0,0)
-  const int boff = (kh * BN + (lane & 31)) * 16;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-  h8 ah[TM], al[TM], bh[TN], bl[TN];
-
-  auto read_frags = [&](int step) {
-    const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
-    const char* B = Bs + (step & 1) * B_BYTES + boff;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
-      al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
-      bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
-    }
-  };
-  // everything a group does for its K-step `step` while the other group computes
-  auto service = [&](int step) {
-    if (step >= nsteps) return;
-    read_frags(step);
-    const int chunk = step / NTAPS, tap = step - chunk * NTAPS;
-    const int r = tap % 3, i = tap / 3;
-    // p.abl (timing ablations only, results wrong): 8 = no activation loads / staging in the loop, 2 = no weight DMA in the loop
-    const bool st = !(p.abl & 8);
-    if (st && chunk + 1 < nchunks && r == 2) write_item(chunk + 1, i);   // (the compiler drains vmcnt for areg here: before the DMA)
-    if (!(p.abl & 2) && g == 0 && step + 1 < nsteps) issue_B(step + 1, (step + 1) & 1, wave, 4);   // slot of step-1: both groups have read it
-    if (st && chunk + 1 < nchunks && r == 0) load_item(chunk + 1, i);    // 2 loads, NEWER than the DMA: see the counted wait
-  };
-
-  // ---- prologue: weight slice 0 and halo tile of chunk 0 staged by all 8 waves; group 0 reads its step-0 fragments ----
-  issue_B(0, 0, wave, 8);
-  if (ps) {
-    for (int c = tid; c < p.Cin; c += NT) { Ss[c] = ps[c]; Ss[p.Cin + c] = psh[c]; }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    load_item(0, i);
-    write_item(0, i);
-  }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (g == 0) service(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  for (int ph = 0; ph < 2 * nsteps; ++ph) {
-    if ((ph & 1) == g) {   // this group's turn on the matrix pipe: K-step (ph - g) / 2
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-      // The weight slice group 0 issued in its last service turn must have landed before the barrier that lets it be read;
-      // activation loads issued behind it in that turn (exactly 2 per wave, at taps 0/3/6) may stay in flight.
-      if (g == 0) {
-        const int sstep = ph >> 1, schunk = sstep / NTAPS, stap = sstep - schunk * NTAPS;
-        if (!(p.abl & 8) && schunk + 1 < nchunks && (stap % 3) == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else {               // service turn: group 1 prepares step ph/2 (computed next phase), group 0 step (ph+1)/2
-      service((ph + 1) >> 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done, staged halo rows written
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-
-  // ---- epilogue (as the 4-wave kernel): C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
-  const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
-  const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
-  const bool has_b = (p.bias != nullptr), has_c = (cadd != nullptr);
-  double* const red = reinterpret_cast<double*>(smem);   // [8 waves][BN][2]
-  const bool want_stats = (p.stats != nullptr);
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + tn * 32 + (lane & 31);
-    const bool nok = (n < Cout);
-    const float add = nok ? ((has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f)) : 0.f;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int oy = oy0 + wave * TM + tm;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        int ox[8];
-        float rv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = half * 8 + q;
-          ox[q] = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          rv[q] = 0.f;
-        }
-        if (rz) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (nok && oy < p.Hout && ox[q] < p.Wout)
-              rv[q] = p.rups ? rz[((oy >> 1) * (p.Wout >> 1) + (ox[q] >> 1)) * p.ldr + n] : rz[(oy * p.Wout + ox[q]) * p.ldr + n];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (nok && oy < p.Hout && ox[q] < p.Wout) {
-            const float v = (acc[tm][tn][half * 8 + q] * p.alpha + add) + rv[q];
-            outz[(oy * p.Wout + ox[q]) * p.ldo + n] = v;
-            if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
-          }
-        }
-      }
-    }
-    if (want_stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (kh == 0) {
-        double* d = red + ((size_t)wave * BN + tn * 32 + (lane & 31)) * 2;
-        d[0] = s1;
-        d[1] = s2;
-      }
-    }
-  }
-  if (want_stats) {
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      if (n0 + c < Cout) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          s1 += red[((size_t)w * BN + c) * 2];
-          s2 += red[((size_t)w * BN + c) * 2 + 1];
-        }
-        double* dst = p.stats + (((size_t)zo * gridDim.x + blockIdx.x) * Cout + n0 + c) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-      }
-    }
-  }
-}
-
-static hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
-  const int gx = ((a.Hout + DuoCfg::PH - 1) / DuoCfg::PH) * ((a.Wout + DuoCfg::PW - 1) / DuoCfg::PW);
-  const int gy = (a.Cout + DuoCfg::BN - 1) / DuoCfg::BN;
-  if (a.Cin > DuoCfg::MAX_CIN || (a.Cin % XKC) != 0) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_duo_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DuoCfg::SMEM);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(igemm_f16x3_duo_kernel, dim3(gx, gy, a.Z), dim3(DuoCfg::NT), DuoCfg::SMEM, s, a);
-  return hipGetLastError();
-}
-
 static bool is_vec(const GemmArgs& a) {
   return (((a.c0 | a.c1 | a.lda0 | a.lda1 | a.Cin) & 15) == 0) && ((((uintptr_t)a.a0) | ((uintptr_t)a.a1)) & 15) == 0 &&
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
@@ -1037,7 +743,7 @@ static int eff_tile_x(const GemmArgs& a) {
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
   return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4 ||
-          t == XT_256x32 || t == XT_512x128_DUO) ? XT_256x128
+          t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -1052,9 +758,6 @@ int gemm_mblocks(const GemmArgs& a) {
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: case XT_256x32:
       bm = 256; break;
-    case XT_512x128_DUO: {
-      return ((a.Hout + DuoCfg::PH - 1) / DuoCfg::PH) * ((a.Wout + DuoCfg::PW - 1) / DuoCfg::PW);
-    }
     case XT_128x128: case 9: bm = 128; break;
     default: bm = 64;
   }
@@ -1099,7 +802,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     if (a.ks == 3) return big ? launch_x<X256x128_3plain, false>(a, s) : launch_x<X64x128_3plain, false>(a, s);
     return big ? launch_x<X256x128_1plain, false>(a, s) : launch_x<X64x128_1plain, false>(a, s);
   }
-  if (a.abl && a.tile == XT_512x128_DUO) return launch_duo(a, s);
   if (a.abl) {   // profiling build of the main tile only
     if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3plain, true, true>(a, s);
     return hipErrorInvalidValue;
@@ -1119,7 +821,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
       case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, false, true>(a, s);   // A/B: static priority
-      case XT_512x128_DUO: return launch_duo(a, s);
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
       case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);
       case 10: return launch_x<X64x128_3t1, true, false, true>(a, s);

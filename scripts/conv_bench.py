@@ -58,15 +58,11 @@ if __name__ == "__main__":
             a = run(8, Ch, C1, 512, 3, tile=0, iters=10)
             b_ = run(8, Ch, C1, 512, 3, tile=4, iters=10)
             print(f"  {Ch}+{C1}->512 @8 r{rnd}: split-K {a[0]*1e3:7.1f} us {a[1]:6.1f} TF   single {b_[0]*1e3:7.1f} us {b_[1]:6.1f} TF", flush=True)
-    print("-- A/B interleaved: 4-wave main tile (1) vs 8-wave role-alternating kernel (13), 4 rounds")
-    for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (128, 128, 0), (64, 256, 0)):
-        for rnd in range(4):
-            r = [run(H, Ch, C1, Ch, 3, tile=t, iters=6)[1] for t in (1, 13)]
-            print(f"  {Ch}+{C1}->{Ch} @{H} round {rnd}: main {r[0]:6.1f}  duo {r[1]:6.1f} TFLOP/s", flush=True)
-    print("-- duo ablations (128->128 @256): abl -> TFLOP/s-equivalent")
-    for abl in (0, 8, 2, 10):
-        ms, tf = run(256, 128, 0, 128, 3, tile=13, abl=abl)
-        print(f"  duo abl={abl:2d}: {ms:8.3f} ms {tf:7.1f}", flush=True)
+    print("-- A/B interleaved: main tile (1) vs + static odd-slot priority (7) vs ring 4 (8), 3 rounds")
+    for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
+        for rnd in range(3):
+            r = [run(H, Ch, C1, Ch, 3, tile=t, iters=6)[1] for t in (1, 7, 8)]
+            print(f"  {Ch}+{C1}->{Ch} @{H} round {rnd}: main {r[0]:6.1f}  sprio {r[1]:6.1f}  ring4 {r[2]:6.1f} TFLOP/s", flush=True)
     print("-- A/B interleaved: 3 taps per barrier (tiles 2,3,4) vs 1 (tiles 9,10,11)")
     for (H, Ch, C1, Co) in ((32, 256, 0, 256), (16, 512, 0, 512), (16, 512, 512, 512), (8, 512, 0, 512), (8, 512, 512, 512)):
         for rnd in range(2):
