@@ -75,13 +75,11 @@ class HipUNet(nn.Module):
 
     def _run(self, x, t, index, t_edit, hs_coeff, delta_h, ignore_timestep, use_mask):
         assert x.shape[2] == x.shape[3] == self.resolution
-        if delta_h is not None or use_mask:
-            raise NotImplementedError("passing a delta_h tensor selects the reference's DiffStyle slerp branch "
-                                      "(models/ddpm/diffusion.py:518-539); only the DeltaBlock path is accelerated")
         eng = self._ready_engine(x)
         apply_edit = bool(index is not None and (t[0] >= t_edit))   # the reference's own host sync (:510)
+        # a delta_h TENSOR replaces the DeltaBlocks by the per-sample slerp mix (:518-539); use_mask only matters there
         return eng.unet_forward(x, t, index=index, apply_edit=apply_edit, hs_coeff=hs_coeff,
-                                ignore_timestep=ignore_timestep)
+                                ignore_timestep=ignore_timestep, delta_h=delta_h, use_mask=use_mask)
 
     # ---- engine plumbing ------------------------------------------------------------------------
     def _drop_engine(self):

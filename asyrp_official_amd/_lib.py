@@ -27,6 +27,8 @@ class AsyrpConfig(C.Structure):
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
+ABI_VERSION = 3   # include/asyrp.h ASYRP_ABI_VERSION
+
 _SIGS = {
     "asyrp_abi_version": (C.c_int, []),
     "asyrp_last_error": (C.c_char_p, []),
@@ -38,8 +40,8 @@ _SIGS = {
     "asyrp_finalize_params": (C.c_int, [_P]),
     "asyrp_num_params": (C.c_int, [_P]),
     "asyrp_param_info": (C.c_int, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
-    "asyrp_unet_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "asyrp_ddim_step": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "asyrp_unet_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "asyrp_ddim_step": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P, _I, _I, _P, _I, _F, _I, _P, _P, _P, _P, _P]),
     "asyrp_run_edit": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "asyrp_device_bytes": (C.c_int64, [_P]),
     "asyrp_profile_enable": (C.c_int, [_P, _I]),
@@ -72,6 +74,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args
+    if lib.asyrp_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI v{lib.asyrp_abi_version()}, this package binds v{ABI_VERSION}: "
+                           "rebuild with `python -m asyrp_official_amd.build`")
     _lib = lib
     return lib
 

@@ -7,6 +7,9 @@ and the editing-strength schedules that sit directly on the two loops (§8f-2).
                     {"0": layer_0.state_dict(), ..., "optimizer": ..., "scheduler": ...}    (diffusion_latent.py:393-404, :674-676)
   hs_coeff          (hs_coeff_origin_h, n_train_step / n_test_step * hs_coeff_delta_h), multi-attribute 1/sqrt(k) scaling
                     (diffusion_latent.py:626, :654, :659); --delta_interpolation sweep (:726-755)
+  global delta-h    --num_mean_of_delta_hs: per-timestep mean of the DeltaBlock outputs over images, entry 0 = mean over
+                    timesteps, stored as checkpoint_latent/{exp}_{n_test}_{n_mean}.pth and re-injected through the
+                    `delta_h=` argument of denoising_step (diffusion_latent.py:516, :528-532, :811-831)
 """
 import os
 
@@ -107,3 +110,74 @@ def edit_sweep(model, x_T, betas, hs_coeffs, **kw):
     Returns [len(hs_coeffs)] tensors [B,3,R,R].  (The strengths share x_T but not the trajectory: they are independent
     batch entries, so this is `len(hs_coeffs)` engine calls on the already-resident weights.)"""
     return [run_edit(model, x_T, betas, invert=False, hs_coeff=tuple(hc), **kw) for hc in hs_coeffs]
+
+
+# ---- global (mean) delta-h ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def generate_stepwise(model, x_T, betas, *, n_gen=40, t_0=999, t_edit=500, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
+                      learn_sigma=False, delta_h_dict=None, ignore_timesteps=False, collect=None, use_mask=False,
+                      dt_lambda=1, noise=None):
+    """save_image's generation loop one denoising_step at a time (diffusion_latent.py:503-534), for the two cases the
+    fused asyrp_run_edit does not cover:
+      collect=<dict>        get_delta_hs: the DeltaBlock output of every step with t >= t_edit is summed into
+                            collect[t] (:528-532); the edit itself still uses the DeltaBlocks;
+      delta_h_dict=<dict>   the stored delta-h tensors are injected instead of evaluating the DeltaBlocks (:516):
+                            delta_h_dict[t] for t >= t_edit, or delta_h_dict[0] at every step with ignore_timesteps.
+    `noise` = [n_eta_steps,B,3,R,R] for the eta=1 tail (else drawn on the device).  Returns x_edit."""
+    from .diffusion_utils import denoising_step
+    from .sampler import timestep_seq
+    seq, seq_next = timestep_seq(n_gen, t_0)
+    x, B, k = x_T, x_T.shape[0], 0
+    for i, j in zip(reversed(seq), reversed(seq_next)):
+        t = torch.full((B,), float(i), device=x.device)
+        t_next = torch.full((B,), float(j), device=x.device)
+        inject = None
+        if delta_h_dict is not None and collect is None:
+            inject = delta_h_dict[0] if ignore_timesteps else (delta_h_dict[int(i)] if i >= t_edit else None)
+            if inject is not None:
+                inject = inject.to(x.device).float().expand(B, -1, -1, -1).contiguous()
+        eta = 1.0 if i < t_addnoise else 0.0
+        nz = None
+        if eta and noise is not None:
+            nz, k = noise[k], k + 1
+        x, _, dh, _ = denoising_step(x, t, t_next, models=model, b=betas, eta=eta, learn_sigma=learn_sigma, index=index,
+                                     t_edit=t_edit, hs_coeff=hs_coeff, delta_h=inject, ignore_timestep=ignore_timesteps,
+                                     use_mask=use_mask, dt_lambda=dt_lambda, noise=nz)
+        if collect is not None and i >= t_edit:
+            collect[int(i)] = dh if collect.get(int(i)) is None else collect[int(i)] + dh
+    return x
+
+
+def finish_mean_delta_hs(collect, n_batches, group=None):
+    """Turn the per-timestep sums of `n_batches` generate_stepwise(collect=...) calls into the reference's global
+    delta-h dictionary (diffusion_latent.py:811-831): every entry divided by the number of batches, and entry 0 = the
+    mean over the timesteps that have one (used with --ignore_timesteps).  With a process group the sums and the batch
+    count are all-reduced first (one [B,C,8,8] all-reduce per edited timestep), so every rank holds the mean over the
+    images of ALL ranks — the only data-path reduction of the whole method."""
+    import torch.distributed as dist
+    out = dict(collect)
+    n = float(n_batches)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        cnt = torch.tensor([n], dtype=torch.float64, device=next(v for v in out.values() if v is not None).device)
+        dist.all_reduce(cnt, group=group)
+        n = float(cnt.item())
+        for k in sorted(k for k, v in out.items() if v is not None):
+            out[k] = out[k].clone()
+            dist.all_reduce(out[k], group=group)
+    for k, v in out.items():
+        if v is not None:
+            out[k] = v / n
+    tot, cnt = None, 0
+    for k in out.keys():          # the reference's own accumulation order (dict order = ascending timestep)
+        if out[k] is None:
+            continue
+        tot = out[k].clone() if tot is None else tot + out[k]
+        cnt += 1
+    if tot is not None:
+        out[0] = tot / cnt
+    return out
+
+
+def mean_delta_path(exp_id, n_test_step, num_mean, root="checkpoint_latent"):
+    """`checkpoint_latent/{exp_id}_{n_test_step}_{num_mean_of_delta_hs}.pth` (diffusion_latent.py:613,831)."""
+    return os.path.join(root, f"{exp_id}_{n_test_step}_{num_mean}.pth")

@@ -22,6 +22,7 @@
 //       projection) + residual -> fp32 NHWC, 128-B contiguous per pixel row of a 32-channel MFMA tile.
 // Reference ops replaced: models/ddpm/diffusion.py:151-170 (ResnetBlock convs + nin_shortcut), :72-110 (Up/Downsample),
 // :179-198 (AttnBlock q,k,v,proj_out 1x1), :236-248 (DeltaBlock 1x1), :356-360/:426-430 (conv_in/conv_out).
+#include <cstdlib>
 #include "kernels.h"
 
 namespace asyrp {
@@ -724,7 +725,14 @@ static int auto_tile_x(const GemmArgs& a) {
   };
   if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
-  if (M >= 256 && blocks(256, 128) >= 512) return XT_256x128;
+  if (M >= 256 && blocks(256, 128) >= 512) {
+    static const int main_tile = [] {   // EXPERIMENT knob: ASYRP_MAIN_TILE=6 runs the big layers on the 8-wave tile
+      const char* e = getenv("ASYRP_MAIN_TILE");
+      const int v = e ? atoi(e) : 0;
+      return (v == XT_256x128W8) ? XT_256x128W8 : XT_256x128;
+    }();
+    return main_tile;
+  }
   // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
   // (measured, profiles/r01_conv_microbench_*.txt); 8x8 layers (M = 64) fall through to 64-pixel tiles
   if (M >= 128 && blocks(128, 128) >= 256) return XT_128x128;
@@ -750,7 +758,7 @@ static int eff_tile_x(const GemmArgs& a) {
 bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
-  return is_vec(a) && eff_tile_x(a) == XT_256x128;
+  return is_vec(a) && (eff_tile_x(a) == XT_256x128 || eff_tile_x(a) == XT_256x128W8);
 }
 
 int gemm_mblocks(const GemmArgs& a) {

@@ -445,6 +445,8 @@ struct Ctx {
   hipStream_t s;
   int B;
   float* tproj = nullptr;   // [B][tproj_total]
+  const float* dh_in = nullptr;   // injected delta-h tensor (NHWC) -> slerp mix instead of the DeltaBlocks
+  int use_mask = 0;
 };
 
 float* P(Ctx& c, const std::string& name) {
@@ -940,7 +942,13 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   Act h;
   TRY(run_layers_i(c, e->mid_block, hs.back(), nullptr, &h));
   *middle = h;
-  if (index >= 0 && apply_edit) {   // :697-704
+  if (index >= 0 && apply_edit && c.dh_in) {   // injected delta_h tensor: unet.py:708-731
+    Act h2;
+    TRY(new_act(c, h.C, h.H, h.W, &h2));
+    HIPCHK(launch_slerp_mix(h.p, c.dh_in, (float)(1.0 - (double)coeff[0]), c.use_mask, c.B, h.H, h.W, h.C, h2.p, c.s));
+    TRY(decoder_i(c, h2, hs, et_mod));
+    drop(c, h2);
+  } else if (index >= 0 && apply_edit) {   // :697-704
     std::vector<Act> deltas(index + 1);
     const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
@@ -1033,7 +1041,13 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   drop(c, m2);
   *middle = h;
 
-  if (index >= 0 && apply_edit) {   // :510-516
+  if (index >= 0 && apply_edit && c.dh_in) {   // injected delta_h tensor: :518-539
+    Act h2;
+    TRY(new_act(c, h.C, h.H, h.W, &h2));
+    HIPCHK(launch_slerp_mix(h.p, c.dh_in, (float)(1.0 - (double)coeff[0]), c.use_mask, c.B, h.H, h.W, h.C, h2.p, c.s));
+    TRY(decoder(c, h2, skips, et_mod));
+    drop(c, h2);
+  } else if (index >= 0 && apply_edit) {   // :510-516
     std::vector<Act> deltas(index + 1);
     const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
@@ -1097,7 +1111,7 @@ int ddim_apply(Ctx& c, const float* x, const Act& et, const Act& et_mod, const f
 // =====================================================================================================
 extern "C" {
 
-int asyrp_abi_version(void) { return 2; }
+int asyrp_abi_version(void) { return ASYRP_ABI_VERSION; }
 
 const char* asyrp_last_error(void) { return g_err.c_str(); }
 
@@ -1271,14 +1285,34 @@ int asyrp_finalize_params(asyrp_engine* e) {
 
 int64_t asyrp_device_bytes(const asyrp_engine* e) { return e ? (int64_t)(e->param_bytes + e->pool.total_bytes) : 0; }
 
+static void bottleneck_shape(const asyrp_engine* e, int* C, int* R) {
+  const asyrp_config& cf = e->cfg;
+  *C = cf.ch * cf.ch_mult[cf.n_levels - 1];
+  *R = cf.resolution >> (cf.n_levels - 1);
+}
+
+// Stage an injected delta-h tensor (NCHW at the boundary) into the engine's NHWC layout; nullptr in -> nullptr out.
+static int stage_delta_in(Ctx& c, const float* delta_h_in, int use_mask, int index, int apply_edit, float** staged) {
+  *staged = nullptr;
+  if (!delta_h_in || index < 0 || !apply_edit) return 0;   // ignored below t_edit / without index, as in the reference
+  int C = 0, R = 0;
+  bottleneck_shape(c.e, &C, &R);
+  if (use_mask && R < 6) return fail(ASYRP_EINVAL, "use_mask needs a bottleneck of at least 6x6 (rows 4..H-2 would be empty)");
+  TRY(c.e->pool.get((size_t)c.B * C * R * R, staged));
+  HIPCHK(launch_nchw_to_nhwc(delta_h_in, *staged, c.B, C, R * R, c.s));
+  c.dh_in = *staged;
+  c.use_mask = use_mask;
+  return 0;
+}
+
 int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, int index, int apply_edit,
-                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* et, float* et_mod,
-                       float* delta_h_out, float* middle_h, void* stream) {
+                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, const float* delta_h_in, int use_mask,
+                       float* et, float* et_mod, float* delta_h_out, float* middle_h, void* stream) {
   TRY(check_ready(e, B));
   if (!x || !t || !et) return fail(ASYRP_EINVAL, "null tensor");
   if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
-  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < index + 2))
-    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < (delta_h_in ? 1 : index + 2)))
+    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries (1 with an injected delta_h)");
   if (index >= 0 && !et_mod) return fail(ASYRP_EINVAL, "et_mod buffer required when index is given");
   HIPCHK(hipSetDevice(e->device));
   Ctx c{e, (hipStream_t)stream, B};
@@ -1287,8 +1321,11 @@ int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, i
   float* xn = nullptr;
   TRY(e->pool.get((size_t)B * HW * cf.in_channels, &xn));
   HIPCHK(launch_nchw_to_nhwc(x, xn, B, cf.in_channels, HW, c.s));
+  float* dh_staged = nullptr;
+  TRY(stage_delta_in(c, delta_h_in, use_mask, index, apply_edit, &dh_staged));
   Act a_et, a_em, a_dh, a_mid;
   TRY(unet_core(c, xn, t, index, apply_edit, hs_coeff_host, ignore_timestep, &a_et, &a_em, &a_dh, &a_mid));
+  if (dh_staged) e->pool.put(dh_staged);
   HIPCHK(launch_nhwc_to_nchw(a_et.p, a_et.C, et, B, a_et.C, HW, c.s));
   if (index >= 0) {
     const Act& src = a_em.p ? a_em : a_et;   // no edit: ε̃ ≡ ε
@@ -1306,13 +1343,13 @@ int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, i
 
 int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, float eta, const float* noise,
                     int learn_sigma, int index, int apply_edit, const float* hs_coeff_host, int n_coeff,
-                    int ignore_timestep, float dt_lambda, int dt_end, float* xt_next, float* x0_t,
-                    float* delta_h_out, float* middle_h, void* stream) {
+                    int ignore_timestep, const float* delta_h_in, int use_mask, float dt_lambda, int dt_end,
+                    float* xt_next, float* x0_t, float* delta_h_out, float* middle_h, void* stream) {
   TRY(check_ready(e, B));
   if (!xt || !xt_next) return fail(ASYRP_EINVAL, "null tensor");
   if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
-  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < index + 2))
-    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  if (index >= 0 && apply_edit && (!hs_coeff_host || n_coeff < (delta_h_in ? 1 : index + 2)))
+    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries (1 with an injected delta_h)");
   const asyrp_config& cf = e->cfg;
   if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
     return fail(ASYRP_EINVAL, "DDIM step expects 3 image channels");
@@ -1330,8 +1367,11 @@ int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, 
     HIPCHK(launch_nchw_to_nhwc(noise, nz, B, 3, HW, c.s));
   }
   hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+  float* dh_staged = nullptr;
+  TRY(stage_delta_in(c, delta_h_in, use_mask, index, apply_edit, &dh_staged));
   Act a_et, a_em, a_dh, a_mid;
   TRY(unet_core(c, xn, e->d_t, index, apply_edit, hs_coeff_host, ignore_timestep, &a_et, &a_em, &a_dh, &a_mid));
+  if (dh_staged) e->pool.put(dh_staged);
   TRY(ddim_apply(c, xn, a_et, a_em, nz, t, t_next, eta, dt_lambda, dt_end, xo, x0o));
   HIPCHK(launch_nhwc_to_nchw(xo, 3, xt_next, B, 3, HW, c.s));
   if (x0_t) HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0_t, B, 3, HW, c.s));

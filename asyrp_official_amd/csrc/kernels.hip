@@ -730,6 +730,76 @@ hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_
 }
 
 // =====================================================================================================
+// Injected delta-h: h2 = slerp(tt, h, |h| * dh / |dh|)  (models/ddpm/diffusion.py:6-40,531-539) or, with use_mask,
+// h2 = slerp(tt, h*m, dh*m) + (1-m)*h with m = 1 on rows 4..H-2, columns 3..4 (:519-529).  One workgroup per sample;
+// the reference's three norms and the dot product are evaluated in its order (norms of h and dh, norm of the rescaled
+// dh, dot of the two unit vectors), each as a fixed-order double reduction.
+// =====================================================================================================
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+__global__ void __launch_bounds__(256) slerp_mix_kernel(const float* h, const float* dh, float tt, int use_mask, int H, int W,
+                                                        int C, float* out) {
+  __shared__ double red[4];
+  const long long per = (long long)H * W * C;
+  const float* hp = h + blockIdx.x * per;
+  const float* dp = dh + blockIdx.x * per;
+  float* op = out + blockIdx.x * per;
+  auto inmask = [&](long long i) {
+    const int pix = (int)(i / C), y = pix / W, x = pix % W;
+    return y >= 4 && y < H - 1 && x >= 3 && x < 5;
+  };
+  double a = 0.0, b = 0.0;
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    const bool m = !use_mask || inmask(i);
+    const float hv = m ? hp[i] : 0.f, dv = m ? dp[i] : 0.f;
+    a += (double)hv * hv;
+    b += (double)dv * dv;
+  }
+  const float nh = sqrtf((float)block_sum(a, red));
+  const float nd = sqrtf((float)block_sum(b, red));
+  // v1 = the second slerp operand: dh*m (mask) or (|h| * dh) / |dh| (norm matched); n1 = its norm
+  auto v1_of = [&](long long i) { return use_mask ? (inmask(i) ? dp[i] : 0.f) : __fdiv_rn(__fmul_rn(nh, dp[i]), nd); };
+  float n1 = nd;
+  if (!use_mask) {
+    double c2 = 0.0;
+    for (long long i = threadIdx.x; i < per; i += blockDim.x) { const float v = v1_of(i); c2 += (double)v * v; }
+    n1 = sqrtf((float)block_sum(c2, red));
+  }
+  double d = 0.0;
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    const float hv = (!use_mask || inmask(i)) ? hp[i] : 0.f;
+    d += (double)__fmul_rn(__fdiv_rn(hv, nh), __fdiv_rn(v1_of(i), n1));
+  }
+  const float dot = (float)block_sum(d, red);
+  const float th0 = acosf(dot), tht = __fmul_rn(th0, tt), sn = sinf(th0);
+  const float s0 = __fdiv_rn(sinf(__fsub_rn(th0, tht)), sn), s1 = __fdiv_rn(sinf(tht), sn);
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    const float hv = hp[i];
+    if (use_mask) {
+      const bool m = inmask(i);
+      const float part = __fadd_rn(__fmul_rn(s0, m ? hv : 0.f), __fmul_rn(s1, m ? dp[i] : 0.f));
+      op[i] = __fadd_rn(part, m ? 0.f : hv);
+    } else {
+      op[i] = __fadd_rn(__fmul_rn(s0, hv), __fmul_rn(s1, v1_of(i)));
+    }
+  }
+}
+
+hipError_t launch_slerp_mix(const float* h, const float* dh, float tt, int use_mask, int B, int H, int W, int C, float* h2,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(slerp_mix_kernel, dim3(B), dim3(256), 0, s, h, dh, tt, use_mask, H, W, C, h2);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
 // 2x2 average pooling of the activated tensor and of the raw tensor (iDDPM down-sampling ResBlock)
 // =====================================================================================================
 __global__ void pool2_kernel(const float* x, int H, int W, int C, const float* scale, const float* shift, float* hp,

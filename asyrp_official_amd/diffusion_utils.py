@@ -40,14 +40,15 @@ def denoising_step(xt, t, t_next, *, models, logvars=None, b, sampling_type='ddi
     """One DDIM step; returns (xt_next, x0_t, delta_h, middle_h) exactly like the reference.
 
     Differences, all loud: only sampling_type='ddim' (the 'ddpm' branch of the reference leaves x0_t
-    undefined, :73-82); `delta_h` tensors / `image_space_noise` are outside the accelerated path;
+    undefined, :73-82); `image_space_noise` is outside the accelerated path; a `delta_h` tensor selects
+    the reference's slerp injection (models/ddpm/diffusion.py:518-539) and is handed back unchanged;
     when eta != 0 the Gaussian noise may be passed as `noise=` (bit-parity with a CPU generator),
     otherwise it is drawn on the GPU with torch.randn_like as the reference does.
     """
     if sampling_type != 'ddim':
         raise NotImplementedError("only sampling_type='ddim' is accelerated")
-    if delta_h is not None or type(image_space_noise) != int or use_mask:
-        raise NotImplementedError("delta_h / image_space_noise / use_mask select DiffStyle branches outside the hot path")
+    if type(image_space_noise) != int:
+        raise NotImplementedError("image_space_noise selects a DiffStyle branch outside the hot path")
     model = _unwrap(models)
     model.set_schedule(b) if getattr(model, "_betas", None) is None or not torch.equal(
         model._betas, b.detach().float().cpu()) else None
@@ -59,5 +60,6 @@ def denoising_step(xt, t, t_next, *, models, logvars=None, b, sampling_type='ddi
     xt_next, x0_t, dh, mid = eng.ddim_step(xt, ti, tn, eta=float(eta), noise=noise if eta != 0 else None,
                                            learn_sigma=learn_sigma, index=index, apply_edit=apply_edit,
                                            hs_coeff=hs_coeff, ignore_timestep=ignore_timestep,
-                                           dt_lambda=float(dt_lambda), dt_end=int(dt_end))
+                                           dt_lambda=float(dt_lambda), dt_end=int(dt_end), delta_h=delta_h,
+                                           use_mask=use_mask)
     return xt_next, x0_t, dh, mid

@@ -118,7 +118,17 @@ class Engine:
         arr = (C.c_float * len(hs))(*hs)
         return arr, len(hs)
 
-    def unet_forward(self, x, t, index=None, apply_edit=False, hs_coeff=(1.0, 1.0), ignore_timestep=False):
+    def _delta_in(self, delta_h, B):
+        if delta_h is None:
+            return None
+        d = _dev_f32(delta_h, "delta_h")
+        want = (B, self.bott_ch, self.bott_res, self.bott_res)
+        if tuple(d.shape) != want:
+            raise ValueError(f"delta_h must have the bottleneck shape {want}, got {tuple(d.shape)}")
+        return d
+
+    def unet_forward(self, x, t, index=None, apply_edit=False, hs_coeff=(1.0, 1.0), ignore_timestep=False,
+                     delta_h=None, use_mask=False):
         x = _dev_f32(x, "x")
         t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
         B = x.shape[0]
@@ -126,32 +136,38 @@ class Engine:
         R, br, bc = self.resolution, self.bott_res, self.bott_ch
         et = torch.empty((B, self.out_channels, R, R), device=x.device, dtype=torch.float32)
         et_mod = torch.empty_like(et) if idx >= 0 else None
-        dh = torch.empty((B, bc, br, br), device=x.device, dtype=torch.float32) if (idx >= 0 and apply_edit) else None
+        din = self._delta_in(delta_h, B)
+        dh = (torch.empty((B, bc, br, br), device=x.device, dtype=torch.float32)
+              if (idx >= 0 and apply_edit and din is None) else None)
         mid = torch.empty((B, bc, br, br), device=x.device, dtype=torch.float32)
         coeff, ncoeff = self._coeff(hs_coeff, idx)
         with torch.cuda.device(self.device_index):
             _lib.check(self.lib.asyrp_unet_forward(self.h, _ptr(x), _ptr(t), B, idx, int(bool(apply_edit)), coeff,
-                                                   ncoeff, int(bool(ignore_timestep)), _ptr(et), _ptr(et_mod),
-                                                   _ptr(dh), _ptr(mid), self._stream()))
-        return et, et_mod, dh, mid
+                                                   ncoeff, int(bool(ignore_timestep)), _ptr(din), int(bool(use_mask)),
+                                                   _ptr(et), _ptr(et_mod), _ptr(dh), _ptr(mid), self._stream()))
+        # with an injected delta_h the reference hands the caller's own tensor back (diffusion.py:580)
+        return et, et_mod, (delta_h if delta_h is not None else dh), mid
 
     def ddim_step(self, xt, t, t_next, *, eta=0.0, noise=None, learn_sigma=False, index=None, apply_edit=False,
-                  hs_coeff=(1.0, 1.0), ignore_timestep=False, dt_lambda=1.0, dt_end=999):
+                  hs_coeff=(1.0, 1.0), ignore_timestep=False, dt_lambda=1.0, dt_end=999, delta_h=None, use_mask=False):
         xt = _dev_f32(xt, "xt")
         noise = _dev_f32(noise, "noise") if noise is not None else None
         B = xt.shape[0]
         idx = -1 if index is None else int(index)
         br, bc = self.bott_res, self.bott_ch
         xn, x0t = torch.empty_like(xt), torch.empty_like(xt)
-        dh = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32) if (idx >= 0 and apply_edit) else None
+        din = self._delta_in(delta_h, B)
+        dh = (torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
+              if (idx >= 0 and apply_edit and din is None) else None)
         mid = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
         coeff, ncoeff = self._coeff(hs_coeff, idx)
         with torch.cuda.device(self.device_index):
             _lib.check(self.lib.asyrp_ddim_step(self.h, _ptr(xt), int(t), int(t_next), B, float(eta), _ptr(noise),
                                                 int(bool(learn_sigma)), idx, int(bool(apply_edit)), coeff, ncoeff,
-                                                int(bool(ignore_timestep)), float(dt_lambda), int(dt_end), _ptr(xn),
+                                                int(bool(ignore_timestep)), _ptr(din), int(bool(use_mask)),
+                                                float(dt_lambda), int(dt_end), _ptr(xn),
                                                 _ptr(x0t), _ptr(dh), _ptr(mid), self._stream()))
-        return xn, x0t, dh, mid
+        return xn, x0t, (delta_h if delta_h is not None else dh), mid
 
     def run_edit(self, x0, seq_inv, seq_gen, *, t_edit, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
                  learn_sigma=False, noise=None, want_latent=False):

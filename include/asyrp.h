@@ -75,7 +75,8 @@ typedef struct asyrp_config {
 
 typedef struct asyrp_engine asyrp_engine;
 
-/* Version of this ABI (bumped on any signature change). */
+/* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
+#define ASYRP_ABI_VERSION 3
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */
@@ -118,23 +119,28 @@ int asyrp_param_info(const asyrp_engine* e, int i, const char** key, int64_t sha
  *               apply_edit == 0 the decoder input is h itself and et_mod == et bit-for-bit (:541-542).
  *   hs_coeff: host pointer, n_coeff = index+2 floats (c0, c1, ...).
  *   ignore_timestep: DeltaBlock gets temb=None (:514).
+ *   delta_h_in (nullable, [B,Cb,Rb,Rb]): the reference's `delta_h=` tensor argument.  When given (and apply_edit), the
+ *               DeltaBlocks are NOT evaluated; the decoder input is slerp(1-c0, h, |h|*delta_h/|delta_h|) per sample
+ *               (:531-539) or, with use_mask != 0, slerp(1-c0, h*m, delta_h*m) + (1-m)*h with m = 1 on rows 4..Rb-2,
+ *               columns 3..4 (:519-529); only hs_coeff[0] is read and delta_h_out is not written (the reference hands
+ *               the caller's tensor back).  This is how diffusion_latent.py:516 applies the global mean delta-h.
  *   outputs: et [B,Cout,R,R]; et_mod [B,Cout,R,R] (nullable); delta_h_out [B,Cb,Rb,Rb] (nullable; the
  *   LAST DeltaBlock's raw output as the reference returns it); middle_h [B,Cb,Rb,Rb] (nullable). */
 int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, int index, int apply_edit,
-                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* et, float* et_mod,
-                       float* delta_h_out, float* middle_h, void* stream);
+                       const float* hs_coeff_host, int n_coeff, int ignore_timestep, const float* delta_h_in, int use_mask,
+                       float* et, float* et_mod, float* delta_h_out, float* middle_h, void* stream);
 
 /* B2 — one fused DDIM step = UNet + update (denoising_step, utils/diffusion_utils.py:24-104,
  * sampling_type='ddim').  t / t_next are host ints shared by the batch (the reference builds
  * them as ones(B)*i, diffusion_latent.py:504-505); t_next = -1 means alpha_bar_next = 1 (:68-69).
  *   eta != 0 requires `noise` [B,3,R,R] (stands in for torch.randn_like, :97).
  *   learn_sigma: eps = first half of the output channels (:47-51).
- *   dt_lambda/dt_end: :99-100.  index/apply_edit/hs_coeff/ignore_timestep as above.
+ *   dt_lambda/dt_end: :99-100.  index/apply_edit/hs_coeff/ignore_timestep/delta_h_in/use_mask as above.
  *   outputs: xt_next, x0_t [B,3,R,R]; delta_h_out, middle_h nullable. */
 int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, float eta, const float* noise,
                     int learn_sigma, int index, int apply_edit, const float* hs_coeff_host, int n_coeff,
-                    int ignore_timestep, float dt_lambda, int dt_end, float* xt_next, float* x0_t,
-                    float* delta_h_out, float* middle_h, void* stream);
+                    int ignore_timestep, const float* delta_h_in, int use_mask, float dt_lambda, int dt_end,
+                    float* xt_next, float* x0_t, float* delta_h_out, float* middle_h, void* stream);
 
 /* The two hot loops back to back (diffusion_latent.py:1034-1045 then :503-520):
  *   x0 [B,3,R,R] --(n_inv-1 inversion steps over seq_inv)--> x_T --(n_gen Asyrp steps over seq_gen)--> x_edit.

@@ -9,6 +9,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from .ddpm import slerp   # improved_ddpm/unet.py:24-60 is the same function as ddpm/diffusion.py:6-40
+
 
 class IDDPMConfig:
     """Arguments of create_model (improved_ddpm/script_util.py:45-99) that shape the network."""
@@ -216,8 +218,6 @@ def _decoder(h, hs, emb, sd, out_plan, cfg):
 def iddpm_forward(sd, cfg, x, timesteps, y=None, index=None, t_edit=400, hs_coeff=(1.0, 1.0), delta_h=None,
                   ignore_timestep=False, use_mask=False):
     """UNetModel.forward (unet.py:676-752): returns (h, h2, delta_h, middle_h); `y` is ignored as in the reference."""
-    if delta_h is not None:
-        raise NotImplementedError("DiffStyle slerp branch (unet.py:706-728) is outside the accelerated path")
     inp, mid, out_plan, _ = block_plan(cfg)
     emb = timestep_embedding(timesteps, cfg.num_channels)
     emb = F.linear(_silu(F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])),
@@ -232,10 +232,20 @@ def iddpm_forward(sd, cfg, x, timesteps, y=None, index=None, t_edit=400, hs_coef
     h2 = None
     if index is not None:
         if timesteps[0] >= t_edit:
-            h2 = h * hs_coeff[0]
-            for i in range(index + 1):
-                delta_h = delta_block(h, None if ignore_timestep else emb, sd, f"layer_{i}")
-                h2 = h2 + delta_h * hs_coeff[i + 1]
+            if delta_h is None:                                  # Asyrp, unet.py:702-706
+                h2 = h * hs_coeff[0]
+                for i in range(index + 1):
+                    delta_h = delta_block(h, None if ignore_timestep else emb, sd, f"layer_{i}")
+                    h2 = h2 + delta_h * hs_coeff[i + 1]
+            elif use_mask:                                       # injected delta_h tensor, masked slerp, unet.py:709-719
+                mask = torch.zeros_like(h)
+                mask[:, :, 4:-1, 3:5] = 1.0
+                h2 = slerp(1 - hs_coeff[0], h * mask, delta_h * mask) + (1 - mask) * h
+            else:                                                # norm-matched slerp, unet.py:722-731
+                n = h.shape[0]
+                hn = h.reshape(n, -1).norm(dim=1).reshape(n, 1, 1, 1)
+                dn = delta_h.reshape(n, -1).norm(dim=1).reshape(n, 1, 1, 1)
+                h2 = slerp(1.0 - hs_coeff[0], h, hn * delta_h / dn)
         else:
             h2 = h
         h2 = _decoder(h2, hs, emb, sd, out_plan, cfg)

@@ -58,6 +58,16 @@ if __name__ == "__main__":
             a = run(8, Ch, C1, 512, 3, tile=0, iters=10)
             b_ = run(8, Ch, C1, 512, 3, tile=4, iters=10)
             print(f"  {Ch}+{C1}->512 @8 r{rnd}: split-K {a[0]*1e3:7.1f} us {a[1]:6.1f} TF   single {b_[0]*1e3:7.1f} us {b_[1]:6.1f} TF", flush=True)
+    print("-- A/B interleaved: 4-wave pipelined main tile (1) vs 8-wave plain-loop tile (6), 5 rounds")
+    for (H, Ch, C1, Co, kw) in ((256, 128, 0, 128, {}), (256, 128, 0, 128, dict(res=1)), (256, 128, 128, 128, {}),
+                                (128, 128, 0, 128, {}), (128, 256, 128, 128, {}), (64, 256, 0, 256, {}), (64, 256, 256, 256, {}),
+                                (128, 128, 0, 128, dict(ups=1, pro=0)), (32, 256, 0, 256, {})):
+        r1, r6 = [], []
+        for rnd in range(5):
+            r1.append(run(H, Ch, C1, Co, 3, tile=1, iters=6, **kw)[1])
+            r6.append(run(H, Ch, C1, Co, 3, tile=6, iters=6, **kw)[1])
+        f = lambda v: " ".join(f"{x:5.0f}" for x in v)
+        print(f"  {Ch}+{C1}->{Co} @{H} {kw}: tile1 [{f(r1)}]  tile6 [{f(r6)}]  median ratio {sorted(r6)[2] / sorted(r1)[2]:.3f}", flush=True)
     print("-- A/B interleaved: main tile (1) vs + static odd-slot priority (7) vs ring 4 (8), 3 rounds")
     for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
         for rnd in range(3):

@@ -8,6 +8,7 @@ and records reference outputs as .npz fixtures next to this script:
   ddpm_small.npz   small DDPM (ch=32, 32x32): forwards, single steps, a 6+6-step edit
   ddpm_celeba.npz  full CelebA-HQ DDPM (256x256, B=1): one single + one dual forward,
                    one Asyrp step, DeltaBlock = hash weights
+  slerp_small.npz  both small UNets with an injected delta_h tensor (slerp branch, +/- use_mask)
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; ~1 min on 8 cores)
 """
@@ -243,6 +244,39 @@ def run_afhq(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_slerp(out):
+    """The injected-delta_h branch of both UNet families (models/ddpm/diffusion.py:518-539, improved_ddpm/unet.py:708-731):
+    a Delta-h TENSOR is passed to forward / denoising_step (how diffusion_latent.py:516 feeds the global mean Delta-h),
+    with and without use_mask.  Same small models / inputs as ddpm_small.npz and iddpm_small.npz."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    torch.set_num_threads(1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    B = 2
+    g = {}
+    dh_in = hash_normal("slerp.delta_h", (B, 64, 8, 8), seed=5)
+    g["input.delta_h"] = dh_in
+    fams = (("ddpm", ref_model(SMALL, synthetic_state_dict(ddpm_param_shapes(SMALL, n_delta=2), seed=7), n_delta=2),
+             hash_normal("small.x", (B, 3, 32, 32), seed=1), False),
+            ("iddpm", ref_iddpm(SMALL_I, synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11), 2),
+             hash_normal("ismall.x", (B, 3, 32, 32), seed=2), True))
+    with torch.no_grad():
+        for name, m, x, ls in fams:
+            t = torch.ones(B) * 701.0
+            for tag, c0, um in (("nomask", 0.7, False), ("mask", 0.7, True), ("nomask_c0", 0.25, False)):
+                et, em, dh, mh = m(x, t, index=0, t_edit=500, hs_coeff=(c0, 1.0), delta_h=dh_in, use_mask=um)
+                assert dh is dh_in
+                g[f"{name}.{tag}.et"], g[f"{name}.{tag}.et_mod"], g[f"{name}.{tag}.middle_h"] = et, em, mh
+            et, em, dh, mh = m(x, torch.ones(B) * 204.0, index=0, t_edit=500, hs_coeff=(0.7, 1.0), delta_h=dh_in)
+            assert torch.equal(et, em)                                   # below t_edit the tensor is ignored (:541-542)
+            xn, x0t, dh, mh = denoising_step(x, t=t, t_next=torch.ones(B) * 675.0, models=m, logvars=np.zeros(1000), b=betas,
+                                             sampling_type="ddim", learn_sigma=ls, eta=0.0, index=0, t_edit=500,
+                                             hs_coeff=(0.7, 1.0), delta_h=dh_in)
+            g[f"{name}.step.xt_next"], g[f"{name}.step.x0_t"] = xn, x0t
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -256,10 +290,12 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
+    if a.only in (None, "slerp"):
+        run_slerp(os.path.join(HERE, "slerp_small.npz"))
     if a.only in (None, "iddpm_small"):
         run_iddpm_small(os.path.join(HERE, "iddpm_small.npz"))
     if a.only in (None, "iddpm_small2"):

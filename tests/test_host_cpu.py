@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/asyrp.h but not exported by libasyrp_hip.so"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes signature table and include/asyrp.h disagree"
-    assert lib.asyrp_abi_version() == 2
+    header = open(os.path.join(ROOT, "include", "asyrp.h")).read()
+    assert lib.asyrp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define ASYRP_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_engine_parameter_inventory_equals_reference_state_dict():
@@ -87,7 +88,7 @@ def test_cpu_tensors_fail_loudly_no_fallback():
     with pytest.raises(AsyrpDeviceError):
         denoising_step(x, torch.ones(1) * 10.0, torch.ones(1) * 5.0, models=m, logvars=None,
                        b=torch.linspace(1e-4, 0.02, 1000))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AsyrpDeviceError):      # the injected-delta_h (slerp) branch has no CPU path either
         m(x, torch.ones(1), index=0, delta_h=torch.zeros(1, 64, 8, 8))
 
 
@@ -130,6 +131,42 @@ def test_two_rank_gloo_shard_and_all_gather(tmp_path, n_total):
     full = torch.arange(n_total * 3 * 4 * 4, dtype=torch.float32).reshape(n_total, 3, 4, 4) * 2.0 + 1.0
     for r in range(2):
         assert torch.equal(torch.load(os.path.join(tmp_path, f"r{r}.pt")), full)
+
+
+def _mean_rank_main(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from asyrp_official_amd.cache import finish_mean_delta_hs
+    g = torch.Generator().manual_seed(5)
+    parts = torch.randn((3, 2, 1, 4, 2, 2), generator=g)        # [batch, timestep, ...]: rank 0 owns batch 0-1, rank 1 batch 2
+    mine = parts[:2] if rank == 0 else parts[2:]
+    collect = {0: None, 499: None, 749: sum(mine[:, 0]), 999: sum(mine[:, 1])}
+    torch.save(finish_mean_delta_hs(collect, len(mine)), os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_global_mean_delta_h_dictionary_single_and_two_rank(tmp_path):
+    """finish_mean_delta_hs == the reference's bookkeeping (diffusion_latent.py:811-831); across ranks the per-timestep
+    sums are all-reduced so every rank holds the mean over all images (the one data-path reduction of the method)."""
+    from asyrp_official_amd.cache import finish_mean_delta_hs, mean_delta_path
+    g = torch.Generator().manual_seed(5)
+    parts = torch.randn((3, 2, 1, 4, 2, 2), generator=g)
+    # the reference's own loop, restated: sums per timestep, /= number of batches, entry 0 = mean over filled timesteps
+    ref = {0: None, 499: None, 749: parts[0, 0] + parts[1, 0] + parts[2, 0], 999: parts[0, 1] + parts[1, 1] + parts[2, 1]}
+    for k in ref:
+        if ref[k] is not None:
+            ref[k] = ref[k] / 3
+    ref[0] = (ref[749] + ref[999]) / 2
+    got = finish_mean_delta_hs({0: None, 499: None, 749: sum(parts[:, 0]), 999: sum(parts[:, 1])}, 3)
+    assert got[499] is None and all(torch.equal(got[k], ref[k]) for k in (0, 749, 999))
+    mp.spawn(_mean_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        m = torch.load(os.path.join(tmp_path, f"m{r}.pt"))
+        assert m[499] is None
+        for k in (0, 749, 999):
+            torch.testing.assert_close(m[k], ref[k], rtol=1e-6, atol=1e-7)
+    assert mean_delta_path("smiling", 40, 20) == "checkpoint_latent/smiling_40_20.pth"
 
 
 def test_iddpm_parameter_inventory_and_factories():

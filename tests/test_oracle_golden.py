@@ -196,3 +196,32 @@ def test_iddpm_imagenet_style_structure():
         et, em, dh, mh = iddpm_forward(sd, SMALL_I2, x, torch.ones(2) * 555.0, index=0, t_edit=500, hs_coeff=(1.0, 0.8))
     for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh), ("fwd_dual.middle_h", mh)):
         assert_close(got, g[name], what=name, **ITIGHT)
+
+
+def test_injected_delta_h_slerp_branch_both_families():
+    """forward / denoising_step with a delta_h TENSOR (diffusion.py:518-539, unet.py:708-731), +/- use_mask."""
+    from conftest import load_golden
+    from oracle import iddpm as oi
+    g = load_golden("slerp_small.npz")
+    sd, x = _small()
+    isd, ix, icfg = _ismall()
+    dh_in = g["input.delta_h"]
+    t = torch.ones(2) * 701.0
+    b = sampler.beta_schedule()
+    cases = (("ddpm", lambda *a, **k: ddpm_forward(sd, SMALL, *a, **k), sampler.make_model(sd, SMALL), x, False, TIGHT),
+             ("iddpm", lambda *a, **k: oi.iddpm_forward(isd, icfg, *a, **k), oi.make_model(isd, icfg), ix, True, ITIGHT))
+    with torch.no_grad():
+        for name, fwd, model, xx, ls, tol in cases:
+            for tag, c0, um in (("nomask", 0.7, False), ("mask", 0.7, True), ("nomask_c0", 0.25, False)):
+                et, em, dh, mh = fwd(xx, t, index=0, t_edit=500, hs_coeff=(c0, 1.0), delta_h=dh_in, use_mask=um)
+                assert dh is dh_in
+                assert_close(et, g[f"{name}.{tag}.et"], what=f"{name} {tag} et", **tol)
+                assert_close(em, g[f"{name}.{tag}.et_mod"], what=f"{name} {tag} et_mod", **tol)
+                assert_close(mh, g[f"{name}.{tag}.middle_h"], what=f"{name} {tag} middle_h", **tol)
+            et, em, _, _ = fwd(xx, torch.ones(2) * 204.0, index=0, t_edit=500, hs_coeff=(0.7, 1.0), delta_h=dh_in)
+            assert torch.equal(et, em)
+            xn, x0t, _, _ = sampler.denoising_step(xx, t, torch.ones(2) * 675.0, model=model, b=b, eta=0.0, index=0, t_edit=500,
+                                                   hs_coeff=(0.7, 1.0), delta_h=dh_in, learn_sigma=ls)
+            assert_close(xn, g[f"{name}.step.xt_next"], what=f"{name} step xt_next", **tol)
+            # x0_t = (xt - et*sqrt(1-at))/sqrt(at) amplifies the forward's summation-order noise by 1/sqrt(at) ~ 14 at t=701
+            assert_close(x0t, g[f"{name}.step.x0_t"], what=f"{name} step x0_t", rtol=1e-5, atol=5e-5)
