@@ -58,16 +58,21 @@ if __name__ == "__main__":
             a = run(8, Ch, C1, 512, 3, tile=0, iters=10)
             b_ = run(8, Ch, C1, 512, 3, tile=4, iters=10)
             print(f"  {Ch}+{C1}->512 @8 r{rnd}: split-K {a[0]*1e3:7.1f} us {a[1]:6.1f} TF   single {b_[0]*1e3:7.1f} us {b_[1]:6.1f} TF", flush=True)
-    print("-- A/B interleaved: 4-wave pipelined main tile (1) vs 8-wave plain-loop tile (6), 5 rounds")
+    print("-- A/B interleaved: 4-wave pipelined tile (1) vs 8-wave tiles: plain loop (6), early loads (14), staggered staging (15)")
+    tiles = (1, 6, 14, 15)
     for (H, Ch, C1, Co, kw) in ((256, 128, 0, 128, {}), (256, 128, 0, 128, dict(res=1)), (256, 128, 128, 128, {}),
-                                (128, 128, 0, 128, {}), (128, 256, 128, 128, {}), (64, 256, 0, 256, {}), (64, 256, 256, 256, {}),
+                                (128, 128, 0, 128, {}), (64, 256, 0, 256, {}), (64, 256, 256, 256, {}),
                                 (128, 128, 0, 128, dict(ups=1, pro=0)), (32, 256, 0, 256, {})):
-        r1, r6 = [], []
+        r = {t: [] for t in tiles}
         for rnd in range(5):
-            r1.append(run(H, Ch, C1, Co, 3, tile=1, iters=6, **kw)[1])
-            r6.append(run(H, Ch, C1, Co, 3, tile=6, iters=6, **kw)[1])
-        f = lambda v: " ".join(f"{x:5.0f}" for x in v)
-        print(f"  {Ch}+{C1}->{Co} @{H} {kw}: tile1 [{f(r1)}]  tile6 [{f(r6)}]  median ratio {sorted(r6)[2] / sorted(r1)[2]:.3f}", flush=True)
+            for t in tiles:
+                r[t].append(run(H, Ch, C1, Co, 3, tile=t, iters=6, **kw)[1])
+        med = {t: sorted(r[t])[2] for t in tiles}
+        print(f"  {Ch}+{C1}->{Co} @{H} {kw}: " + "  ".join(f"t{t} {med[t]:5.1f} ({med[t] / med[1]:.3f})" for t in tiles), flush=True)
+    print("-- ablations of the 8-wave tile (128->128 @256): abl mask -> TFLOP/s-equivalent (2 = no weight DMA, 8 = no activation loads/staging)")
+    for abl in (32, 32 | 8, 32 | 2, 32 | 2 | 8):
+        ms, tf = run(256, 128, 0, 128, 3, tile=6, abl=abl, iters=6)
+        print(f"  abl={abl & 31:2d}: {ms:8.3f} ms {tf:7.1f}", flush=True)
     print("-- A/B interleaved: main tile (1) vs + static odd-slot priority (7) vs ring 4 (8), 3 rounds")
     for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
         for rnd in range(3):
