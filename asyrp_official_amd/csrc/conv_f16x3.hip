@@ -100,10 +100,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (PIPE, TS=1)
 // SPRIO: static asymmetric priority: the wave in the odd hardware wave slot of each SIMD runs at priority 2 for its whole
 //       life, so the two co-resident workgroups of a CU do not convoy on the matrix pipe (A/B experiment)
-// VAR (8-wave plain loop, A/B): 1 = the next chunk's activation loads are issued two taps before they are staged;
-//       2 = every wave loads/stages its halo items at its own tap of the chunk (staggered), so the staging VALU bursts of
-//       the four waves of a SIMD never coincide and the matrix pipe always has a wave to issue from
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false, int VAR = 0>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   if (SPRIO) {
@@ -174,7 +171,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   float4 areg[NA][2];
   float4 sreg[4];   // scale[8], shift[8] of this thread's channels in the chunk being staged
 
-  auto gload_A = [&](int chunk, int sel = -1) {   // sel >= 0: only staging item `sel`
+  auto gload_A = [&](int chunk) {
     const int c = chunk * XKC + hf * 8;
     if (VEC) {
       const float* __restrict__ base;
@@ -198,7 +195,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        if (sel >= 0 && sel != i) continue;
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         const int sp = aoff[i];
         if (sp >= 0) {
@@ -236,7 +232,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     }
   };
 
-  auto write_A = [&](int chunk, int buf, int sel = -1) {
+  auto write_A = [&](int chunk, int buf) {
     const int c = chunk * XKC + hf * 8;
     if (LOWREG && VEC && ps && !(SC && chunk >= nch1)) {
       sreg[0] = *reinterpret_cast<const float4*>(ps + c);
@@ -248,7 +244,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (aoff[i] == -2 || (sel >= 0 && sel != i)) continue;
+      if (aoff[i] == -2) continue;
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
       if (aoff[i] >= 0 && !(abl & 1) && !(SC && chunk >= nch1)) {
@@ -463,19 +459,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       const bool next_a = (chunk + 1 < nchunks);
       if (more && !(abl & 2)) issue_B(step + 1, (step + 1) & 1);
       if (!LOWREG && first_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
-      constexpr bool EARLY_OK = LOWREG && VAR >= 1 && NTAPS == 9;
-      const bool EARLY = EARLY_OK && !scph;
-      // VAR 2: this wave's load / stage taps of the chunk (item 0: every wave; item 1: the waves that own one)
-      const int st0 = 1 + (((wave & 3) * 2 + (wave >> 2)) & 7), st1 = 1 + ((st0 + 3) & 7);
-      const bool has1 = (NA > 1) && (wave * 64 + NT < NU);
-      if (EARLY && next_a && !(abl & 8)) {   // issued after this step's weight DMA: the end-of-step vmcnt(0) covers both
-        if (VAR == 1) {
-          if (tap == NTAPS - 3) gload_A(chunk + 1);
-        } else {
-          if (tap == st0 - 1) gload_A(chunk + 1, 0);
-          if (has1 && tap == st1 - 1) gload_A(chunk + 1, 1);
-        }
-      }
 
       {
         const int tapA = scph ? NTAPS / 2 : tap;
@@ -545,13 +528,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         }
       }
 
-      if (EARLY && VAR == 2) {
-        if (next_a && !(abl & 8)) {
-          if (tap == st0) write_A(chunk + 1, (chunk + 1) & 1, 0);
-          if (has1 && tap == st1) write_A(chunk + 1, (chunk + 1) & 1, 1);
-        }
-      } else if (last_tap && next_a && !(abl & 8)) {
-        if (LOWREG && !EARLY) gload_A(chunk + 1);
+      if (last_tap && next_a && !(abl & 8)) {
+        if (LOWREG) gload_A(chunk + 1);
         write_A(chunk + 1, (chunk + 1) & 1);
       }
       if (!(abl & 16)) {
@@ -714,7 +692,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false, int VAR = 0>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -731,24 +709,19 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO, VAR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO, VAR>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
-// the 256x128 tile the big layers run on.  EXPERIMENT knob: ASYRP_MAIN_TILE=6|14|15 selects an 8-wave loop variant
-int gemm_main_tile() {
-  static const int main_tile = [] {
-    const char* e = getenv("ASYRP_MAIN_TILE");
-    const int v = e ? atoi(e) : 0;
-    return (v == XT_256x128W8 || v == XT_W8_V1 || v == XT_W8_V2) ? v : XT_256x128;
-  }();
-  return main_tile;
-}
+// the 256x128 tile the big 3x3 layers run on: 8 waves (4 per SIMD with two workgroups per CU), plain per-tap loop.
+// Interleaved A/B against the 4-wave software-pipelined tile: +6...12 % per layer, +5 % on the whole edit
+// (profiles/r01_conv_microbench_w8*.txt)
+int gemm_main_tile() { return XT_256x128W8; }
 
 // tile ids of the f16x3 family (GemmArgs.tile / profile variant)
 static int auto_tile_x(const GemmArgs& a) {
@@ -766,7 +739,7 @@ static int auto_tile_x(const GemmArgs& a) {
   };
   if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
-  if (M >= 256 && blocks(256, 128) >= 512) return gemm_main_tile();
+  if (M >= 256 && blocks(256, 128) >= 512) return a.ks == 3 ? gemm_main_tile() : XT_256x128;
   // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
   // (measured, profiles/r01_conv_microbench_*.txt); 8x8 layers (M = 64) fall through to 64-pixel tiles
   if (M >= 128 && blocks(128, 128) >= 256) return XT_128x128;
@@ -785,7 +758,7 @@ static int eff_tile_x(const GemmArgs& a) {
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
   return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4 ||
-          t == XT_256x32 || t == XT_W8_V1 || t == XT_W8_V2) ? XT_256x128
+          t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -793,14 +766,13 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_W8_V1 || t == XT_W8_V2);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: case XT_256x32:
-    case XT_W8_V1: case XT_W8_V2:
       bm = 256; break;
     case XT_128x128: case 9: bm = 128; break;
     default: bm = 64;
@@ -853,12 +825,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
-    switch (tile) {
-      case XT_256x128W8: return launch_x<X256x128w8_3, true, false, false, true>(a, s);
-      case XT_W8_V1: return launch_x<X256x128w8_3, true, false, false, true, false, 1>(a, s);
-      case XT_W8_V2: return launch_x<X256x128w8_3, true, false, false, true, false, 2>(a, s);
-      default: return launch_x<X256x128_3, true, false, true, true>(a, s);
-    }
+    return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
     if (a.stride == 2) return launch_x<X64x128_3s2, true, false, true>(a, s);
@@ -870,8 +837,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_W8_V1: return launch_x<X256x128w8_3, true, false, false, false, false, 1>(a, s);
-      case XT_W8_V2: return launch_x<X256x128w8_3, true, false, false, false, false, 2>(a, s);
       case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, false, true>(a, s);   // A/B: static priority
       case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
       case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);

@@ -468,7 +468,7 @@ void drop(Ctx& c, Act& a) {
 }
 
 int variant_of(const GemmArgs& g) {
-  if (g.math == MATH_F16X3 && g.wpk) return 10000 + gemm_resolve_tile_x(g) * 1000 + g.ks * 100 + g.stride * 10;
+  if (g.math == MATH_F16X3 && g.wpk) return 100000 + gemm_resolve_tile_x(g) * 1000 + g.ks * 100 + g.stride * 10;
   return gemm_resolve_tile(g) * 1000 + g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0);
 }
 

@@ -54,7 +54,7 @@ enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_12
 // ids 7..11 are A/B variants kept for scripts/conv_bench.py (ring depth 3 / 4 on the main tile; single-tap steps on the small tiles)
 enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
        XT_256x128_PLAIN = 7 /* A/B: weight ring of 3 */, XT_256x128_R4 = 8 /* A/B: weight ring of 4 */,
-       XT_256x32 = 12 /* conv_out: Cout <= 32 */, XT_W8_V1 = 14, XT_W8_V2 = 15 /* 8-wave loop variants (A/B) */ };
+       XT_256x32 = 12 /* conv_out: Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);

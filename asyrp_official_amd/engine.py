@@ -198,10 +198,11 @@ class Engine:
         _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(var), C.byref(ms), C.byref(n), C.byref(fl),
                                                C.byref(by), C.byref(ams), C.byref(afl)))
         v = var.value
-        fam, tid = v // 10000, (v // 1000) % 10
+        fam, tid = v // 100000, (v // 1000) % 100
         ks, stride = (v // 100) % 10, (v // 10) % 10
         if fam == 1:
-            tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2)}.get(tid, (0,) * 4)
+            tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
+                    12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
             name = "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
         else:
             tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)

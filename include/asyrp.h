@@ -163,9 +163,10 @@ int64_t asyrp_device_bytes(const asyrp_engine* e);
 int asyrp_profile_enable(asyrp_engine* e, int on);
 /* After a device sync: statistics of the implicit-GEMM launches recorded since the last read.
  * The DOMINANT variant (largest accumulated time) is reported in full:
- *   *variant = family*10000 + tile*1000 + ksize*100 + stride*10 + transposedB
+ *   *variant = family*100000 + tile*1000 + ksize*100 + stride*10 + transposedB
  *     family 0 = igemm_f32 (tile: 1=128x128, 2=128x64, 3=64x64, 4=128x32),
- *     family 1 = igemm_f16x3 (tile: 1=256x128, 2=128x128, 3=64x128, 4=64x64, 5=256x64),
+ *     family 1 = igemm_f16x3 (tile: 1=256x128 4-wave pipelined, 2=128x128, 3=64x128, 4=64x64, 5=256x64,
+ *                             6=256x128 8-wave (the default for big 3x3 layers), 12=256x32),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */

@@ -58,8 +58,8 @@ if __name__ == "__main__":
             a = run(8, Ch, C1, 512, 3, tile=0, iters=10)
             b_ = run(8, Ch, C1, 512, 3, tile=4, iters=10)
             print(f"  {Ch}+{C1}->512 @8 r{rnd}: split-K {a[0]*1e3:7.1f} us {a[1]:6.1f} TF   single {b_[0]*1e3:7.1f} us {b_[1]:6.1f} TF", flush=True)
-    print("-- A/B interleaved: 4-wave pipelined tile (1) vs 8-wave tiles: plain loop (6), early loads (14), staggered staging (15)")
-    tiles = (1, 6, 14, 15)
+    print("-- A/B interleaved: 4-wave pipelined tile (1) vs 8-wave plain-loop tile (6)")
+    tiles = (1, 6)
     for (H, Ch, C1, Co, kw) in ((256, 128, 0, 128, {}), (256, 128, 0, 128, dict(res=1)), (256, 128, 128, 128, {}),
                                 (128, 128, 0, 128, {}), (64, 256, 0, 256, {}), (64, 256, 256, 256, {}),
                                 (128, 128, 0, 128, dict(ups=1, pro=0)), (32, 256, 0, 256, {})):
