@@ -97,15 +97,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # ASYRP_BENCH_BACKEND=gloo is a DRY-RUN knob for a box with fewer GPUs than ranks (ranks share devices, the final
+    # gather is staged through host memory): it exercises the launcher / barrier / max-over-ranks code, not RCCL
+    backend = os.environ.get("ASYRP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL
+        else:
+            dist.init_process_group(backend=backend)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from asyrp_official_amd import DDPM, i_DDPM, run_edit
     from asyrp_official_amd.diffusion_utils import get_beta_schedule
@@ -131,8 +138,8 @@ def main():
     def one_step():
         x_edit = run_edit(model, x0, betas, n_inv=N_INV, n_gen=N_GEN, t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0,
                           hs_coeff=(1.0, 1.0), learn_sigma=learn_sigma)
-        if world > 1:
-            x_edit = gather_shards(x_edit, B * world)   # the one collective of the path
+        if world > 1:   # the one collective of the path
+            x_edit = gather_shards(x_edit, B * world) if backend == "nccl" else gather_shards(x_edit.cpu(), B * world).to(dev)
         return x_edit
 
     for _ in range(a.warmup):
@@ -156,7 +163,7 @@ def main():
         eng.profile_enable(False)
         prof = eng.profile_read()
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite output"

@@ -13,3 +13,9 @@ cd $GRAFT_REPO_ROOT
 timeout 300 python scripts/conv_bench.py 32 > $OUT/conv_bench.txt 2>&1
 find gpurun_out/$TAG gpurun_out/${TAG}_traffic -name '*.csv' -size +1M -delete
 cat gpurun_out/${TAG}_traffic/traffic_summary.json
+# other BASELINE configs on one GPU, and a 2-rank dry run of the launcher path (ranks share the GPU, gloo; not a perf number)
+for cfg in afhq imagenet; do
+  (timeout 300 python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline 2> $OUT/bench_$cfg.err | tail -1) > $OUT/bench_$cfg.json
+done
+(ASYRP_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --batch 4 --no-kernel-events 2> $OUT/bench_2rank_dryrun.err | tail -1) > $OUT/bench_2rank_dryrun.json
+cat $OUT/bench_afhq.json $OUT/bench_imagenet.json $OUT/bench_2rank_dryrun.json | cut -c1-400
