@@ -62,6 +62,21 @@ struct XCfg {
   static constexpr int MINW = ((SMEM <= 76 * 1024) ? 2 : 1) * (NW / 4);
 };
 
+// MFMA row i (0..31) of a wave's 32-pixel group (two rows of a 16-wide tile, row pitch 18 pixels in the LDS halo) ->
+// pixel index within the group.  `ds_read_b128` is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}
+// (+32): with the identity mapping the second tile row starts 2 bank-quads after the first and every group has a 2-way
+// conflict (A-fragment reads take 8 LDS cycles instead of 4: SQ_LDS_BANK_CONFLICT = 1/4..1/3 of SQ_LDS_IDX_ACTIVE).
+// This bijection gives each lane group 16 distinct bank quads: {row0 x0-7, row1 x6-13} and {row0 x8-15, row1 x14,15,0-5}.
+__device__ __forceinline__ int row_perm32(int i) {
+  if (i < 4) return i;
+  if (i < 12) return i + 4;
+  if (i < 16) return i - 8;
+  if (i < 18) return i + 14;
+  if (i < 20) return i - 2;
+  if (i < 28) return i + 2;
+  return i - 10;
+}
+
 __device__ __forceinline__ float silu_fast(float v) {
   // x * sigmoid(x) (models/ddpm/diffusion.py:63-65) with v_exp_f32 / v_rcp_f32 (<= 2 ulp each)
   const float e = __expf(-v);
@@ -115,6 +130,10 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   // 8-wave workgroups run 4 waves per SIMD inside a 128-VGPR budget: activation loads are issued right before their
   // staging pass (not a chunk ahead) and fragments are fetched per MFMA pass; the other three waves hide the latency.
   constexpr bool LOWREG = (NW >= 8);
+  // conflict-free A-fragment reads (row_perm32) on the 4-wave tiles: SQ_LDS_BANK_CONFLICT 23 % -> 0, +1.1...1.7 % on the
+  // pipelined 256x128 tile.  The 8-wave tile measured 2 % SLOWER with it (interleaved A/B on one box,
+  // profiles/r01_conv_microbench_perm1.txt / _scv1.txt) and keeps the identity map.
+  constexpr bool RPERM = (KS == 3 && STRIDE == 1 && PW == 16) && !LOWREG;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // weight ring first: LDS-DMA destinations go through M0, kept below 64 KB; the halo tiles behind it are written by ds_write
@@ -292,7 +311,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   int apix[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const int m = (wm * TM + tm) * 32 + (lane & 31);
+    const int m = (wm * TM + tm) * 32 + (RPERM ? row_perm32(lane & 31) : (lane & 31));
     if (KS == 1) {
       apix[tm] = m;
     } else {
@@ -459,6 +478,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       const bool next_a = (chunk + 1 < nchunks);
       if (more && !(abl & 2)) issue_B(step + 1, (step + 1) & 1);
       if (!LOWREG && first_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
+      // 8-wave tile with the fused shortcut: the next chunk's loads go out ahead of this (last) tap's MFMA passes and are
+      // staged behind them (16 live registers for one tap) -- in the shortcut phase every step is a chunk's last tap.
+      // Measured as the ratio fused / plain launch time of one edit step (rocprofv3, same box): 0.880 this way, 0.891
+      // with the loads right before the staging pass, 0.938 issued a whole step ahead, 0.906-0.910 on the 4-wave
+      // pipelined tile (profiles/r01n_kernel_stats_*.csv)
+      if (LOWREG && SC && last_tap && next_a && !(abl & 8)) gload_A(chunk + 1);
 
       {
         const int tapA = scph ? NTAPS / 2 : tap;
@@ -529,7 +554,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       }
 
       if (last_tap && next_a && !(abl & 8)) {
-        if (LOWREG) gload_A(chunk + 1);
+        if (LOWREG && !SC) gload_A(chunk + 1);
         write_A(chunk + 1, (chunk + 1) & 1);
       }
       if (!(abl & 16)) {
@@ -571,7 +596,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int ri = (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int m = (wm * TM + tm) * 32 + (RPERM ? row_perm32(ri) : ri);
           int pixel;
           bool ok;
           if (KS == 1) {
@@ -605,7 +631,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int r = half * 8 + q;
-            const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int ri = (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int m = (wm * TM + tm) * 32 + (RPERM ? row_perm32(ri) : ri);
             pixel[q] = (KS == 1) ? (m0 + m) : ((oy0 + m / PW) * p.Wout + ox0 + (m % PW));
           }
           float rv[8];
@@ -643,7 +670,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int ri = (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int m = (wm * TM + tm) * 32 + (RPERM ? row_perm32(ri) : ri);
           int pixel;
           bool ok;
           if (KS == 1) {
