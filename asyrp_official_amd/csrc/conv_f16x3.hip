@@ -113,16 +113,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
 // SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (PIPE, TS=1)
-// SPRIO: static asymmetric priority: the wave in the odd hardware wave slot of each SIMD runs at priority 2 for its whole
-//       life, so the two co-resident workgroups of a CU do not convoy on the matrix pipe (A/B experiment)
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
-  if (SPRIO) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (hwid & 1) __builtin_amdgcn_s_setprio(2);
-  }
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, PW = T::PW, TW = T::TW;
   constexpr int NPIX = T::NPIX, A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, NA = T::NA, NTAPS = T::NTAPS;
@@ -720,7 +713,7 @@ static bool is_vec(const GemmArgs& a) {
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, bool SPRIO = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -737,12 +730,12 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, a.Z), block(T::NT);
   static bool attr_set = false;
   if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, SPRIO>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, a);
   return hipGetLastError();
 }
 
@@ -785,8 +778,7 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = gemm_resolve_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128_PLAIN || t == XT_256x128_R4 ||
-          t == XT_256x32) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -800,9 +792,9 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128_PLAIN: case XT_256x128_R4: case XT_256x32:
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x32:
       bm = 256; break;
-    case XT_128x128: case 9: bm = 128; break;
+    case XT_128x128: bm = 128; break;
     default: bm = 64;
   }
   if (a.ks == 1) return (a.Hout * a.Wout + bm - 1) / bm;
@@ -818,14 +810,9 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   // last parameter: weight-slice ring size of the pipelined loop (slices stay in flight for RB-1 K-steps); the small
   // tiles have short K-steps (3-6 MFMAs per wave), so they need the deeper ring to cover the L2 latency of a slice
   using X256x128_3 = XCfg<4, 1, 2, 4, 3, 1, 2>;      // ring of 2: deeper rings measured equal (3) or slower (4) on this tile
-  using X256x128_3r2 = XCfg<4, 1, 2, 4, 3, 1, 3>;
-  using X256x128_3r4 = XCfg<4, 1, 2, 4, 3, 1, 4>;
   using X128x128_3 = XCfg<2, 2, 2, 2, 3, 1, 2, 3>;    // 11.5 KB x 2 halo + 2 x 24 KB weight slots = 71 KB: 2 workgroups per CU
   using X64x128_3 = XCfg<2, 2, 1, 2, 3, 1, 2, 3>;     // 61 KB
   using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 3, 3>;      // 49 KB
-  using X128x128_3t1 = XCfg<2, 2, 2, 2, 3, 1, 4>;     // single-tap variants kept for A/B (tile ids 9..11)
-  using X64x128_3t1 = XCfg<2, 2, 1, 2, 3, 1, 4>;
-  using X64x64_3t1 = XCfg<2, 2, 1, 1, 3, 1, 4>;
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
   using X256x32_3 = XCfg<4, 1, 2, 1, 3, 1, 2, 1>;     // conv_out (Cout = 3 / 6): 32-wide N tile, 6 MFMAs per wave per K-step
@@ -847,7 +834,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     return big ? launch_x<X256x128_1plain, false>(a, s) : launch_x<X64x128_1plain, false>(a, s);
   }
   if (a.abl) {   // profiling build of the main tile only
-    if (a.ks == 3 && a.stride == 1 && (tile == XT_256x128 || tile == XT_256x128_PLAIN)) return launch_x<X256x128_3plain, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true>(a, s);
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true>(a, s);
     return hipErrorInvalidValue;
   }
@@ -865,11 +852,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128_PLAIN: return launch_x<X256x128_3, true, false, true, false, true>(a, s);   // A/B: static priority
-      case XT_256x128_R4: return launch_x<X256x128_3r4, true, false, true>(a, s);      // A/B: ring of 4
-      case 9: return launch_x<X128x128_3t1, true, false, true>(a, s);
-      case 10: return launch_x<X64x128_3t1, true, false, true>(a, s);
-      case 11: return launch_x<X64x64_3t1, true, false, true>(a, s);
     }
   } else {
     switch (tile) {

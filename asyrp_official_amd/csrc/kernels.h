@@ -51,10 +51,10 @@ enum { MATH_F16X3 = 0, MATH_F32 = 1 };
 
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 
-// ids 7..11 are A/B variants kept for scripts/conv_bench.py (ring depth 3 / 4 on the main tile; single-tap steps on the small tiles)
+// tile ids of the f16x3 family: 1 = 256x128, 4 waves, software-pipelined loop (big 1x1 layers; 3x3 A/B reference);
+// 6 = 256x128, 8 waves, per-tap loop (the big 3x3 layers and their fused shortcut); 12 = conv_out
 enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
-       XT_256x128_PLAIN = 7 /* A/B: weight ring of 3 */, XT_256x128_R4 = 8 /* A/B: weight ring of 4 */,
-       XT_256x32 = 12 /* conv_out: Cout <= 32 */ };
+       XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);

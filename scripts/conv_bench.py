@@ -73,16 +73,6 @@ if __name__ == "__main__":
     for abl in (32, 32 | 8, 32 | 2, 32 | 2 | 8):
         ms, tf = run(256, 128, 0, 128, 3, tile=6, abl=abl, iters=6)
         print(f"  abl={abl & 31:2d}: {ms:8.3f} ms {tf:7.1f}", flush=True)
-    print("-- A/B interleaved: main tile (1) vs + static odd-slot priority (7) vs ring 4 (8), 3 rounds")
-    for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
-        for rnd in range(3):
-            r = [run(H, Ch, C1, Ch, 3, tile=t, iters=6)[1] for t in (1, 7, 8)]
-            print(f"  {Ch}+{C1}->{Ch} @{H} round {rnd}: main {r[0]:6.1f}  sprio {r[1]:6.1f}  ring4 {r[2]:6.1f} TFLOP/s", flush=True)
-    print("-- A/B interleaved: 3 taps per barrier (tiles 2,3,4) vs 1 (tiles 9,10,11)")
-    for (H, Ch, C1, Co) in ((32, 256, 0, 256), (16, 512, 0, 512), (16, 512, 512, 512), (8, 512, 0, 512), (8, 512, 512, 512)):
-        for rnd in range(2):
-            r = [run(H, Ch, C1, Co, 3, tile=t, iters=8)[1] for t in (2, 9, 3, 10, 4, 11)]
-            print(f"  {Ch}+{C1}->{Co} @{H} r{rnd}: 128x128 {r[0]:6.1f}/{r[1]:6.1f}  64x128 {r[2]:6.1f}/{r[3]:6.1f}  64x64 {r[4]:6.1f}/{r[5]:6.1f}", flush=True)
     print("-- tile sweep, 128->128 @64 and 512->512 @16 (f16x3)")
     for (H, Ch) in ((256, 128), (64, 256), (16, 512), (8, 512), (32, 256)):
         for tile in (1, 2, 3, 4, 6):
