@@ -168,6 +168,18 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite output"
 
+    # seconds per step of the two loops separately, outside the timed region: 3 fused steps of each kind
+    def phase_ms(t, t_next, **kw):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(3):
+            eng.ddim_step(x0, t, t_next, learn_sigma=learn_sigma, **kw)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0_) / 3
+    phases = {"inversion_step": phase_ms(486, 512),
+              "generation_step_t>=t_edit(dual decoder)": phase_ms(742, 717, index=0, apply_edit=True, hs_coeff=(1.0, 1.0)),
+              "generation_step_t<t_edit": phase_ms(256, 230, index=0, apply_edit=False, hs_coeff=(1.0, 1.0))}
+
     if rank == 0:
         images = B * world * a.steps
         res = {
@@ -181,6 +193,10 @@ def main():
                                    f" 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
                                    f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
                        "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)"},
+            "phase_ms_per_step": phases,
+            # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
+            "generation_only_images_per_s": B * world / (1e-3 * (20 * phases["generation_step_t>=t_edit(dual decoder)"] +
+                                                                  20 * phases["generation_step_t<t_edit"])),
         }
         if prof and prof["launches"]:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
