@@ -17,7 +17,10 @@
 //   B (weights, pre-split and pre-packed at load time in exactly the LDS image order):
 //       global_load_lds_dwordx4 (LDS-DMA, no VGPRs) one (chunk,tap) slice [u=4][BN][8 x f16] per K-step, double buffered.
 //   MFMA: per K-step (16 channels of one tap) each wave issues TM*TN*3 v_mfma_f32_32x32x16_f16 from
-//       (TM+TN)*2 ds_read_b128 fragments; "unit-major" LDS layout makes both fragment reads bank-conflict free.
+//       (TM+TN)*2 ds_read_b128 fragments; "unit-major" LDS layout: B-fragment reads conflict-free, A-fragment reads
+//       conflict-free with the row permutation below (4-wave tiles).
+//   Two loop organisations: 8 waves per workgroup with a plain per-tap loop (4 waves per SIMD hide the latencies; the
+//       default for the big 3x3 layers) and 4 waves with a software-pipelined loop (all other tiles) -- DESIGN.md 3.1.
 //   Epilogue: acc * alpha (undoes the power-of-two operand scales) + bias + per-image channel vector (timestep
 //       projection) + residual -> fp32 NHWC, 128-B contiguous per pixel row of a 32-channel MFMA tile.
 // Reference ops replaced: models/ddpm/diffusion.py:151-170 (ResnetBlock convs + nin_shortcut), :72-110 (Up/Downsample),
@@ -112,7 +115,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // PIPE: software-pipelined K-loop (4-wave tiles): the per-step barrier sits between MFMA pass 2 and pass 3, the next
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
-// SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (PIPE, TS=1)
+// SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (TS=1);
+//       launched on the 8-wave tile (plain loop); the pipelined loop keeps its implementation for A/B
 template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
