@@ -772,7 +772,7 @@ static int auto_tile_x(const GemmArgs& a) {
   return XT_64x64;
 }
 
-int gemm_resolve_tile_x(const GemmArgs& a) {
+static int requested_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   return a.tile ? a.tile : auto_tile_x(a);
 }
@@ -780,11 +780,13 @@ int gemm_resolve_tile_x(const GemmArgs& a) {
 // the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
 static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
-  const int t = gemm_resolve_tile_x(a);
+  const int t = requested_tile_x(a);
   if (is_vec(a)) return t;
   return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
+
+int gemm_resolve_tile_x(const GemmArgs& a) { return eff_tile_x(a); }
 
 bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;

@@ -60,7 +60,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatch
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s);
 int gemm_resolve_tile(const GemmArgs& a);     // TILE_* the fp32 launcher will pick
-int gemm_resolve_tile_x(const GemmArgs& a);   // XT_* the f16x3 launcher will pick
+int gemm_resolve_tile_x(const GemmArgs& a);   // XT_* of the kernel the f16x3 launcher will run for `a`
 // f16x3 weight image: [ceil(Cin/16)*ks*ks][4][roundup(Cout,128)][8] halfs
 size_t f16x3_packed_halfs(int cout, int cin, int ks);
 hipError_t launch_pack_f16x3(const float* w_dev /*[Cout][Cin][ks][ks]*/, void* dst, int cout, int cin, int ks,
