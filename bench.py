@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; f16/bf16 MFMA ~2500 TFLOP/s
 F32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2500.0
+# measured on this chip with random operands, bare MFMA stream (scripts/calib/mfma_peak.hip -> profiles/r01_calib_mfma_peak.txt):
+# the power envelope caps v_mfma_f32_32x32x16_f16 at 1.66 PFLOP/s (2.46 with zero operands)
+F16_MFMA_MEASURED_RANDOM_TFLOPS = 1657.0
 T_EDIT, T_0, N_INV, N_GEN = 500, 999, 40, 40
 
 CELEBA = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16],
@@ -214,6 +217,8 @@ def main():
                                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / prof["launches"],
                                "flops_per_launch": prof["flops"] / prof["launches"],
                                "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
+                               "frac_of_measured_mfma_ceiling": (ach / (F16_MFMA_MEASURED_RANDOM_TFLOPS / 3.0)
+                                                                 if prof["family"] == "f16x3" else None),
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
         # HBM traffic of the dominant kernel: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of
