@@ -27,7 +27,7 @@ class AsyrpConfig(C.Structure):
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
-ABI_VERSION = 3   # include/asyrp.h ASYRP_ABI_VERSION
+ABI_VERSION = 4   # include/asyrp.h ASYRP_ABI_VERSION
 
 _SIGS = {
     "asyrp_abi_version": (C.c_int, []),
@@ -43,7 +43,10 @@ _SIGS = {
     "asyrp_unet_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "asyrp_ddim_step": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _I, _I, _I, _P, _I, _I, _P, _I, _F, _I, _P, _P, _P, _P, _P]),
     "asyrp_run_edit": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "asyrp_run_inversion": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "asyrp_get_temb": (C.c_int, [_P, _P, _I, _P, _P]),
     "asyrp_device_bytes": (C.c_int64, [_P]),
+    "asyrp_profile_table": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "asyrp_profile_enable": (C.c_int, [_P, _I]),
     "asyrp_profile_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -37,6 +37,26 @@ def precompute_pairs(model, x0, betas, *, n_inv=40, t_0=999, learn_sigma=False):
     return [[x0c[i:i + 1].clone(), xr[i:i + 1].clone(), xl[i:i + 1].clone()] for i in range(x0.shape[0])]
 
 
+@torch.no_grad()
+def inversion_trace(model, x0, betas, *, n_inv=40, t_0=999, learn_sigma=False, window=50):
+    """Engine half of the reference's LPIPS(t) table builder (`compute_lpips_distance`, diffusion_latent.py:1239-1276): DDIM
+    inversion of x0 over n_inv timesteps yielding (t_next, x_{t_next}, x0_t) for EVERY step, so the caller can feed both to
+    LPIPS exactly as the reference does (`loss_fn_alex(x, x0)`, `loss_fn_alex(x0_t, x0)`).  The walk is cut into windows of
+    `window` steps (asyrp_run_inversion taps) so n_inv = 1000 needs 2 x window x B images of device memory, not 2000 x B."""
+    from .sampler import timestep_seq
+    model.set_schedule(betas)
+    eng = model._ready_engine(x0)
+    seq = timestep_seq(n_inv, t_0)[0]
+    x, k = x0, 0
+    while k < len(seq) - 1:
+        n = min(window, len(seq) - 1 - k)
+        sub = seq[k:k + n + 1]
+        x, x_tap, x0t_tap = eng.run_inversion(x, sub, learn_sigma=learn_sigma, tap_first=0, tap_count=n)
+        for i in range(n):
+            yield seq[k + i + 1], x_tap[i], x0t_tap[i]
+        k += n
+
+
 def save_pairs(path, pairs):
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     torch.save([[t.detach().cpu() for t in triple] for triple in pairs], path)

@@ -45,10 +45,15 @@ struct ParamSpec {
   }
 };
 
-// ---- device workspace pool: size-keyed free lists; single in-order stream makes immediate reuse safe ----
+// ---- device workspace pool: size-keyed free lists.  Immediate reuse of a returned buffer is safe because every launch of
+// an engine goes to ONE in-order stream: the engine binds to the stream of its first compute call and, when a later call
+// arrives on another stream, makes that stream wait (event) for everything enqueued on the previous one before any
+// buffer is handed out again (bind_stream below).  `live_` tracks what an ABI call has taken and not yet returned, so
+// an early error return cannot leak workspace: every ABI entry point ends with reclaim(). ----
 struct Pool {
   std::multimap<size_t, float*> free_;
   std::unordered_map<float*, size_t> size_;
+  std::unordered_map<float*, char> live_;
   size_t total_bytes = 0;
   int get(size_t nfloats, float** out) {
     if (nfloats == 0) nfloats = 1;
@@ -57,6 +62,7 @@ struct Pool {
     if (it != free_.end()) {
       *out = it->second;
       free_.erase(it);
+      live_[*out] = 1;
       return 0;
     }
     float* p = nullptr;
@@ -64,18 +70,25 @@ struct Pool {
     if (e != hipSuccess) return fail(ASYRP_EHIP, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
     size_[p] = nfloats;
     total_bytes += nfloats * sizeof(float);
+    live_[p] = 1;
     *out = p;
     return 0;
   }
   void put(float* p) {
     if (!p) return;
     auto it = size_.find(p);
-    if (it != size_.end()) free_.emplace(it->second, p);
+    if (it != size_.end() && live_.erase(p)) free_.emplace(it->second, p);
+  }
+  // end of an ABI call: whatever an error path left outstanding goes back to the free lists
+  void reclaim() {
+    for (auto& kv : live_) free_.emplace(size_[kv.first], kv.first);
+    live_.clear();
   }
   void destroy() {
     for (auto& kv : size_) (void)hipFree(kv.first);
     size_.clear();
     free_.clear();
+    live_.clear();
     total_bytes = 0;
   }
 };
@@ -104,7 +117,11 @@ struct asyrp_engine {
   std::unordered_map<std::string, int> spec_idx;
   std::vector<std::vector<float>> host;
   std::vector<char> loaded;
+  std::vector<char> dirty;    // loaded since the last finalize: only these tensors (and what is fused from them) are re-packed
   bool finalized = false;
+  hipStream_t bound_stream = nullptr;   // stream of the previous compute call (workspace reuse is ordered on it)
+  bool has_bound = false;
+  hipEvent_t bind_ev = nullptr;
 
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
   struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; };
@@ -472,30 +489,40 @@ int variant_of(const GemmArgs& g) {
   return gemm_resolve_tile(g) * 1000 + g.ks * 100 + g.stride * 10 + (g.bT ? 1 : 0);
 }
 
-int run_gemm(Ctx& c, const GemmArgs& g) {
+// Bracket one launch with HIP events on the launch stream when profiling is on (bench.py's roofline objects).
+// variant ids: GEMM families as documented at asyrp_profile_read; 200000 + T = fused attention over T tokens.
+template <class F>
+int run_timed(Ctx& c, int variant, double flops, double bytes, F&& launch) {
   asyrp_engine* e = c.e;
-  if (e->prof_on) {
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!e->ev_free.empty()) {
-      ev = e->ev_free.back();
-      e->ev_free.pop_back();
-    } else {
-      HIPCHK(hipEventCreate(&ev.first));
-      HIPCHK(hipEventCreate(&ev.second));
-    }
-    ProfRec r;
-    r.a = ev.first;
-    r.b = ev.second;
-    r.variant = variant_of(g);
-    gemm_work(g, &r.flops, &r.bytes);
-    HIPCHK(hipEventRecord(r.a, c.s));
-    HIPCHK(launch_gemm(g, c.s));
-    HIPCHK(hipEventRecord(r.b, c.s));
-    e->prof.push_back(r);
+  if (!e->prof_on) {
+    HIPCHK(launch());
     return 0;
   }
-  HIPCHK(launch_gemm(g, c.s));
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!e->ev_free.empty()) {
+    ev = e->ev_free.back();
+    e->ev_free.pop_back();
+  } else {
+    HIPCHK(hipEventCreate(&ev.first));
+    HIPCHK(hipEventCreate(&ev.second));
+  }
+  ProfRec r;
+  r.a = ev.first;
+  r.b = ev.second;
+  r.variant = variant;
+  r.flops = flops;
+  r.bytes = bytes;
+  HIPCHK(hipEventRecord(r.a, c.s));
+  HIPCHK(launch());
+  HIPCHK(hipEventRecord(r.b, c.s));
+  e->prof.push_back(r);
   return 0;
+}
+
+int run_gemm(Ctx& c, const GemmArgs& g) {
+  double fl = 0, by = 0;
+  if (c.e->prof_on) gemm_work(g, &fl, &by);
+  return run_timed(c, c.e->prof_on ? variant_of(g) : 0, fl, by, [&]() { return launch_gemm(g, c.s); });
 }
 
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
@@ -1075,6 +1102,25 @@ __global__ void fill_kernel(float* p, float v, int n) {
   if (i < n) p[i] = v;
 }
 
+// Workspace buffers are recycled without waiting, which is only safe on one in-order stream: when the caller switches
+// streams between calls, the new stream first waits for everything the previous call enqueued.
+int bind_stream(asyrp_engine* e, hipStream_t s) {
+  if (e->has_bound && e->bound_stream != s) {
+    if (!e->bind_ev) HIPCHK(hipEventCreateWithFlags(&e->bind_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->bind_ev, e->bound_stream));
+    HIPCHK(hipStreamWaitEvent(s, e->bind_ev, 0));
+  }
+  e->bound_stream = s;
+  e->has_bound = true;
+  return 0;
+}
+
+// RAII: every ABI compute call returns its outstanding workspace on ANY exit path
+struct PoolGuard {
+  asyrp_engine* e;
+  ~PoolGuard() { if (e) e->pool.reclaim(); }
+};
+
 int check_ready(asyrp_engine* e, int B) {
   if (!e) return fail(ASYRP_EINVAL, "null engine");
   if (!e->finalized) return fail(ASYRP_ESTATE, "asyrp_finalize_params has not been called");
@@ -1135,6 +1181,7 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   for (size_t i = 0; i < e->specs.size(); ++i) e->spec_idx[e->specs[i].key] = (int)i;
   e->host.resize(e->specs.size());
   e->loaded.assign(e->specs.size(), 0);
+  e->dirty.assign(e->specs.size(), 0);
   *out = e;
   return 0;
 }
@@ -1149,6 +1196,7 @@ void asyrp_destroy(asyrp_engine* e) {
   for (auto& kv : e->xw) (void)hipFree(kv.second.p);
   if (e->d_freqs) (void)hipFree(e->d_freqs);
   if (e->d_t) (void)hipFree(e->d_t);
+  if (e->bind_ev) (void)hipEventDestroy(e->bind_ev);
   for (auto& r : e->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& ev : e->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   e->pool.destroy();
@@ -1177,6 +1225,7 @@ int asyrp_load_param(asyrp_engine* e, const char* key, const float* host_data, c
     if (s.shape[d] != shape[d]) return fail(ASYRP_EKEY, std::string("shape mismatch for ") + key);
   e->host[it->second].assign(host_data, host_data + s.numel());
   e->loaded[it->second] = 1;
+  e->dirty[it->second] = 1;
   e->finalized = false;
   return 0;
 }
@@ -1203,26 +1252,39 @@ int asyrp_finalize_params(asyrp_engine* e) {
     if (!e->loaded[i]) return fail(ASYRP_EKEY, "parameter not loaded: " + e->specs[i].key);
   HIPCHK(hipDeviceSynchronize());
   if (!e->d_t) HIPCHK(hipMalloc(&e->d_t, sizeof(float) * e->max_batch));
+  // Only tensors loaded since the previous finalize (and the images fused from them) are re-packed: a DeltaBlock update
+  // (another checkpoint/*.pth, or one optimiser step) costs four small uploads, not a re-pack of the whole UNet.
+  auto isd = [&](const std::string& key) {
+    auto it = e->spec_idx.find(key);
+    return it != e->spec_idx.end() && e->dirty[it->second];
+  };
   // temb projections of every ResnetBlock / DeltaBlock -> one [O_total][temb_ch] matrix
-  std::vector<float> tw, tb;
-  e->tproj_off.clear();
-  int off = 0;
   // per-block timestep projections: DDPM `<block>.temb_proj`, iDDPM `<block>.emb_layers.1`
   const char* tsuf = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".emb_layers.1" : ".temb_proj";
   const std::string tw_suf = std::string(tsuf) + ".weight", tb_suf = std::string(tsuf) + ".bias";
-  for (auto& s : e->specs) {
-    if (!ends_with(s.key, tw_suf)) continue;
-    const std::string p = s.key.substr(0, s.key.size() - tw_suf.size());
-    const auto& w = hostp(e, s.key);
-    const auto& b = hostp(e, p + tb_suf);
-    e->tproj_off[p] = off;
-    tw.insert(tw.end(), w.begin(), w.end());
-    tb.insert(tb.end(), b.begin(), b.end());
-    off += (int)s.shape[0];
+  {
+    bool any = e->tproj_off.empty();
+    for (auto& s : e->specs)
+      if ((ends_with(s.key, tw_suf) || ends_with(s.key, tb_suf)) && isd(s.key)) any = true;
+    if (any) {
+      std::vector<float> tw, tb;
+      e->tproj_off.clear();
+      int off = 0;
+      for (auto& s : e->specs) {
+        if (!ends_with(s.key, tw_suf)) continue;
+        const std::string p = s.key.substr(0, s.key.size() - tw_suf.size());
+        const auto& w = hostp(e, s.key);
+        const auto& b = hostp(e, p + tb_suf);
+        e->tproj_off[p] = off;
+        tw.insert(tw.end(), w.begin(), w.end());
+        tb.insert(tb.end(), b.begin(), b.end());
+        off += (int)s.shape[0];
+      }
+      e->tproj_total = off;
+      TRY(upload(e, "__tproj.weight", tw));
+      TRY(upload(e, "__tproj.bias", tb));
+    }
   }
-  e->tproj_total = off;
-  TRY(upload(e, "__tproj.weight", tw));
-  TRY(upload(e, "__tproj.bias", tb));
   for (auto& s : e->specs) {
     const auto& v = hostp(e, s.key);
     if (ends_with(s.key, tw_suf) || ends_with(s.key, tb_suf)) continue;
@@ -1232,8 +1294,11 @@ int asyrp_finalize_params(asyrp_engine* e) {
       const std::string p = s.key.substr(0, s.key.size() - strlen(".weight"));
       if (ends_with(p, ".q")) {   // fuse q|k|v into one [Cin][3C] operand
         const std::string ap = p.substr(0, p.size() - 2);
-        std::vector<float> w((size_t)cin * 3 * cout), b((size_t)3 * cout);
         const char* names[3] = {".q", ".k", ".v"};
+        bool any = false;
+        for (int t = 0; t < 3; ++t) any = any || isd(ap + names[t] + ".weight") || isd(ap + names[t] + ".bias");
+        if (!any) continue;
+        std::vector<float> w((size_t)cin * 3 * cout), b((size_t)3 * cout);
         for (int t = 0; t < 3; ++t) {
           const auto& wt = hostp(e, ap + names[t] + ".weight");
           const auto& bt = hostp(e, ap + names[t] + ".bias");
@@ -1255,15 +1320,18 @@ int asyrp_finalize_params(asyrp_engine* e) {
       } else if (ends_with(p, ".k") || ends_with(p, ".v")) {
         continue;
       } else {
-        TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
-        if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+        if (isd(s.key)) {
+          TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
+          if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+        }
         // a ResnetBlock / ResBlock with a 1x1 shortcut: fused image (second conv ++ shortcut) and fused bias
         const char* c2 = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".out_layers.3" : ".conv2";
         const char* sk = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".skip_connection" : ".nin_shortcut";
         if (e->math == MATH_F16X3 && k == 3 && ends_with(p, c2)) {
           const std::string blk = p.substr(0, p.size() - strlen(c2));
           auto sit = e->spec_idx.find(blk + sk + ".weight");
-          if (sit != e->spec_idx.end()) {
+          if (sit != e->spec_idx.end() &&
+              (isd(s.key) || isd(p + ".bias") || isd(blk + sk + ".weight") || isd(blk + sk + ".bias"))) {
             const ParamSpec& ss = e->specs[sit->second];
             TRY(pack_x3_fused(e, s.key, v, cout, cin, hostp(e, ss.key), (int)ss.shape[1]));
             std::vector<float> fb = hostp(e, p + ".bias");
@@ -1276,9 +1344,10 @@ int asyrp_finalize_params(asyrp_engine* e) {
     } else {
       const std::string p = s.key.substr(0, s.key.rfind('.'));
       if (ends_with(p, ".q") || ends_with(p, ".k") || ends_with(p, ".v")) continue;   // folded into qkv.bias
-      TRY(upload(e, s.key, v));
+      if (isd(s.key)) TRY(upload(e, s.key, v));
     }
   }
+  std::fill(e->dirty.begin(), e->dirty.end(), 0);
   e->finalized = true;
   return 0;
 }
@@ -1316,6 +1385,8 @@ int asyrp_unet_forward(asyrp_engine* e, const float* x, const float* t, int B, i
   if (index >= 0 && !et_mod) return fail(ASYRP_EINVAL, "et_mod buffer required when index is given");
   HIPCHK(hipSetDevice(e->device));
   Ctx c{e, (hipStream_t)stream, B};
+  PoolGuard guard{e};
+  TRY(bind_stream(e, c.s));
   const asyrp_config& cf = e->cfg;
   const int HW = cf.resolution * cf.resolution;
   float* xn = nullptr;
@@ -1355,6 +1426,8 @@ int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, 
     return fail(ASYRP_EINVAL, "DDIM step expects 3 image channels");
   HIPCHK(hipSetDevice(e->device));
   Ctx c{e, (hipStream_t)stream, B};
+  PoolGuard guard{e};
+  TRY(bind_stream(e, c.s));
   const int HW = cf.resolution * cf.resolution;
   float *xn, *xo, *x0o, *nz = nullptr;
   TRY(e->pool.get((size_t)B * HW * 3, &xn));
@@ -1398,6 +1471,8 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
     return fail(ASYRP_EINVAL, "edit loop expects 3 image channels");
   HIPCHK(hipSetDevice(e->device));
   Ctx c{e, (hipStream_t)stream, B};
+  PoolGuard guard{e};
+  TRY(bind_stream(e, c.s));
   const int HW = cf.resolution * cf.resolution;
   const size_t nx = (size_t)B * HW * 3;
   float *xa, *xb, *nz = nullptr;
@@ -1446,6 +1521,67 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
   return 0;
 }
 
+// DDIM inversion with a per-step read-out: the engine half of the reference's LPIPS(t) table builder
+// (diffusion_latent.py:1239-1276 runs denoising_step over seq_inv and feeds x and x0_t of EVERY step to LPIPS).
+int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv, int n_inv, int learn_sigma,
+                        int tap_first, int tap_count, float* x_tap, float* x0t_tap, float* x_last, void* stream) {
+  TRY(check_ready(e, B));
+  if (!x0 || !seq_inv || n_inv < 2) return fail(ASYRP_EINVAL, "bad argument");
+  if (tap_count < 0 || tap_first < 0 || tap_first + tap_count > n_inv - 1)
+    return fail(ASYRP_EINVAL, "tap window outside the n_inv-1 inversion steps");
+  if (tap_count > 0 && !x_tap && !x0t_tap) return fail(ASYRP_EINVAL, "tap window without a tap buffer");
+  const asyrp_config& cf = e->cfg;
+  if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
+    return fail(ASYRP_EINVAL, "inversion loop expects 3 image channels");
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  PoolGuard guard{e};
+  TRY(bind_stream(e, c.s));
+  const int HW = cf.resolution * cf.resolution;
+  const size_t nx = (size_t)B * HW * 3;
+  float *xa, *xb, *x0o = nullptr;
+  TRY(e->pool.get(nx, &xa));
+  TRY(e->pool.get(nx, &xb));
+  if (x0t_tap) TRY(e->pool.get(nx, &x0o));
+  HIPCHK(launch_nchw_to_nhwc(x0, xa, B, 3, HW, c.s));
+  for (int k = 1; k < n_inv; ++k) {
+    const int t = seq_inv[k - 1], tn = seq_inv[k];
+    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    Act a_et, a_em, a_dh, a_mid;
+    TRY(unet_core(c, xa, e->d_t, -1, 0, nullptr, 0, &a_et, &a_em, &a_dh, &a_mid));
+    const int slot = (k - 1) - tap_first;
+    const bool tap = slot >= 0 && slot < tap_count;
+    TRY(ddim_apply(c, xa, a_et, a_em, nullptr, t, tn, 0.f, 1.f, 999, xb, (tap && x0t_tap) ? x0o : nullptr));
+    drop(c, a_et);
+    drop(c, a_mid);
+    std::swap(xa, xb);
+    if (tap && x_tap) HIPCHK(launch_nhwc_to_nchw(xa, 3, x_tap + (size_t)slot * nx, B, 3, HW, c.s));
+    if (tap && x0t_tap) HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0t_tap + (size_t)slot * nx, B, 3, HW, c.s));
+  }
+  if (x_last) HIPCHK(launch_nhwc_to_nchw(xa, 3, x_last, B, 3, HW, c.s));
+  return 0;
+}
+
+// DDPM.get_temb (models/ddpm/diffusion.py:464-470): temb = dense1(swish(dense0(sinusoid(t)))); for the iDDPM family the
+// same network is `time_embed(timestep_embedding(t))` (models/improved_ddpm/unet.py:688).
+int asyrp_get_temb(asyrp_engine* e, const float* t, int B, float* temb_out, void* stream) {
+  TRY(check_ready(e, B));
+  if (!t || !temb_out) return fail(ASYRP_EINVAL, "null tensor");
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  PoolGuard guard{e};
+  TRY(bind_stream(e, c.s));
+  float* act = nullptr;
+  TRY(e->pool.get((size_t)B * e->temb_ch, &act));
+  const bool iddpm = e->cfg.family == ASYRP_FAMILY_IDDPM;
+  const char* n0 = iddpm ? "time_embed.0" : "temb.dense.0";
+  const char* n1 = iddpm ? "time_embed.2" : "temb.dense.1";
+  HIPCHK(launch_temb_mlp(t, e->d_freqs, e->n_freqs, iddpm ? 0 : 1, P(c, std::string(n0) + ".weight"),
+                         P(c, std::string(n0) + ".bias"), P(c, std::string(n1) + ".weight"), P(c, std::string(n1) + ".bias"),
+                         e->cfg.ch, e->temb_ch, temb_out, act, B, c.s));
+  return 0;
+}
+
 int asyrp_profile_enable(asyrp_engine* e, int on) {
   if (!e) return fail(ASYRP_EINVAL, "null engine");
   e->prof_on = on != 0;
@@ -1481,6 +1617,34 @@ int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launc
   if (all_ms) *all_ms = tms;
   if (all_flops) *all_flops = tfl;
   return 0;
+}
+
+// Every kernel family recorded since the last read, one row each (bench.py's per-family table).  Does NOT reset the
+// record: call asyrp_profile_read afterwards.  Returns the number of rows written (<= max_rows), negative on error.
+int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms, int64_t* launches, double* flops,
+                        double* bytes) {
+  if (!e || max_rows < 0) return fail(ASYRP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  struct Acc { double ms = 0, fl = 0, by = 0; int64_t n = 0; };
+  std::map<int, Acc> acc;
+  for (auto& r : e->prof) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+    Acc& a = acc[r.variant];
+    a.ms += t; a.fl += r.flops; a.by += r.bytes; a.n += 1;
+  }
+  int n = 0;
+  for (auto& kv : acc) {
+    if (n >= max_rows) break;
+    if (variants) variants[n] = kv.first;
+    if (ms) ms[n] = kv.second.ms;
+    if (launches) launches[n] = kv.second.n;
+    if (flops) flops[n] = kv.second.fl;
+    if (bytes) bytes[n] = kv.second.by;
+    ++n;
+  }
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------------

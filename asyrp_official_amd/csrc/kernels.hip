@@ -334,12 +334,18 @@ static hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
   }
   const int gy = (a.Cout + T::BN - 1) / T::BN;
   dim3 grid(gx, gy, a.Z), block(T::NT);
-  static bool attr_set = false;
-  if (!attr_set && T::SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  // per-device (the attribute lives in the device's code object); set once per process and device, under a lock-free
+  // idempotent flag: two threads racing here both set the same value
+  static bool attr_set[16] = {};
+  if (T::SMEM > 64 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
   }
   hipLaunchKernelGGL(igemm_f32_kernel<T>, grid, block, T::SMEM, s, a);
   return hipGetLastError();

@@ -35,8 +35,8 @@ class DDPM(HipUNet):
         self._init_params(max_batch, conv_math)
 
     def get_temb(self, t):
-        raise NotImplementedError("get_temb is only used by the reference's image_space_noise branch "
-                                  "(utils/diffusion_utils.py:62), which is outside the accelerated path")
+        """models/ddpm/diffusion.py:464-470: dense1(swish(dense0(get_timestep_embedding(t, ch)))) -> [B, 4*ch]."""
+        return self._ready_engine(t).get_temb(t)
 
     def forward(self, x, t, index=None, t_edit=400, hs_coeff=(1.0, 1.0), delta_h=None, ignore_timestep=False,
                 use_mask=False):

@@ -127,9 +127,23 @@ class Engine:
             raise ValueError(f"delta_h must have the bottleneck shape {want}, got {tuple(d.shape)}")
         return d
 
+    def _image(self, x, name, like=None):
+        """float32 GPU tensor of shape [B, in_channels, R, R] on this engine's device (the kernels index by these sizes)."""
+        x = _dev_f32(x, name)
+        want = (self.cfg.in_channels, self.resolution, self.resolution)
+        if x.dim() != 4 or tuple(x.shape[1:]) != want:
+            raise ValueError(f"{name} must be [B, {want[0]}, {want[1]}, {want[2]}], got {tuple(x.shape)}")
+        if like is not None and tuple(x.shape) != tuple(like.shape):
+            raise ValueError(f"{name} must have the shape of the image batch {tuple(like.shape)}, got {tuple(x.shape)}")
+        if x.shape[0] < 1 or x.shape[0] > self.max_batch:
+            raise ValueError(f"batch {x.shape[0]} outside [1, max_batch={self.max_batch}]")
+        if x.device.index != self.device_index:
+            raise AsyrpDeviceError(f"{name} lives on {x.device}, the engine on cuda:{self.device_index}")
+        return x
+
     def unet_forward(self, x, t, index=None, apply_edit=False, hs_coeff=(1.0, 1.0), ignore_timestep=False,
                      delta_h=None, use_mask=False):
-        x = _dev_f32(x, "x")
+        x = self._image(x, "x")
         t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
         B = x.shape[0]
         idx = -1 if index is None else int(index)
@@ -150,8 +164,8 @@ class Engine:
 
     def ddim_step(self, xt, t, t_next, *, eta=0.0, noise=None, learn_sigma=False, index=None, apply_edit=False,
                   hs_coeff=(1.0, 1.0), ignore_timestep=False, dt_lambda=1.0, dt_end=999, delta_h=None, use_mask=False):
-        xt = _dev_f32(xt, "xt")
-        noise = _dev_f32(noise, "noise") if noise is not None else None
+        xt = self._image(xt, "xt")
+        noise = self._image(noise, "noise", like=xt) if noise is not None else None
         B = xt.shape[0]
         idx = -1 if index is None else int(index)
         br, bc = self.bott_res, self.bott_ch
@@ -171,12 +185,15 @@ class Engine:
 
     def run_edit(self, x0, seq_inv, seq_gen, *, t_edit, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
                  learn_sigma=False, noise=None, want_latent=False):
-        x0 = _dev_f32(x0, "x0")
+        x0 = self._image(x0, "x0")
         B = x0.shape[0]
         idx = -1 if index is None else int(index)
         si = (C.c_int32 * max(len(seq_inv), 1))(*[int(v) for v in seq_inv])
         sg = (C.c_int32 * len(seq_gen))(*[int(v) for v in seq_gen])
-        noise = _dev_f32(noise, "noise") if noise is not None else None
+        if noise is not None:
+            noise = _dev_f32(noise, "noise")
+            if noise.dim() != 5 or tuple(noise.shape[1:]) != tuple(x0.shape):
+                raise ValueError(f"noise must be [n_eta_steps, {', '.join(map(str, x0.shape))}], got {tuple(noise.shape)}")
         n_noise = 0 if noise is None else int(noise.shape[0])
         x_T = torch.empty_like(x0) if want_latent else None
         x_edit = torch.empty_like(x0)
@@ -187,9 +204,61 @@ class Engine:
                                                _ptr(noise), n_noise, _ptr(x_T), _ptr(x_edit), self._stream()))
         return (x_edit, x_T) if want_latent else x_edit
 
+    def run_inversion(self, x0, seq_inv, *, learn_sigma=False, tap_first=0, tap_count=0, want_x=True, want_x0t=True):
+        """DDIM inversion with a per-step read-out (asyrp_run_inversion): returns (x_last, x_tap, x0t_tap), the taps shaped
+        [tap_count, B, 3, R, R] (None when not requested / tap_count == 0)."""
+        x0 = self._image(x0, "x0")
+        B = x0.shape[0]
+        si = (C.c_int32 * len(seq_inv))(*[int(v) for v in seq_inv])
+        shape = (int(tap_count),) + tuple(x0.shape)
+        x_tap = torch.empty(shape, device=x0.device, dtype=torch.float32) if (tap_count and want_x) else None
+        x0t_tap = torch.empty(shape, device=x0.device, dtype=torch.float32) if (tap_count and want_x0t) else None
+        x_last = torch.empty_like(x0)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_run_inversion(self.h, _ptr(x0), B, si, len(seq_inv), int(bool(learn_sigma)),
+                                                    int(tap_first), int(tap_count), _ptr(x_tap), _ptr(x0t_tap),
+                                                    _ptr(x_last), self._stream()))
+        return x_last, x_tap, x0t_tap
+
+    def get_temb(self, t):
+        t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
+        out = torch.empty((t.shape[0], self.cfg.ch * 4), device=t.device, dtype=torch.float32)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_get_temb(self.h, _ptr(t), int(t.shape[0]), _ptr(out), self._stream()))
+        return out
+
     # ---- profiling --------------------------------------------------------------------------------
     def profile_enable(self, on=True):
         _lib.check(self.lib.asyrp_profile_enable(self.h, int(bool(on))))
+
+    @staticmethod
+    def variant_name(v):
+        """Kernel name (as rocprofv3 prints it) and family of a profile variant id (include/asyrp.h)."""
+        fam, tid = v // 100000, (v // 1000) % 100
+        ks, stride = (v // 100) % 10, (v // 10) % 10
+        if fam == 2:
+            return "attention", "asyrp::attn_f16x3_kernel (T=%d)" % (v - 200000)
+        if fam == 1:
+            tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
+                    12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
+            return "f16x3", "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
+        tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
+        return "f32", "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
+
+    def profile_table(self, max_rows=64):
+        """Per-kernel-family rows recorded since the last profile_read (does not reset the record)."""
+        var = (C.c_int * max_rows)()
+        ms, fl, by = (C.c_double * max_rows)(), (C.c_double * max_rows)(), (C.c_double * max_rows)()
+        n = (C.c_int64 * max_rows)()
+        rows = self.lib.asyrp_profile_table(self.h, max_rows, var, ms, n, fl, by)
+        if rows < 0:
+            _lib.check(rows)
+        out = []
+        for i in range(rows):
+            fam, name = self.variant_name(var[i])
+            out.append(dict(variant=int(var[i]), family=fam, kernel=name, ms=float(ms[i]), launches=int(n[i]),
+                            flops=float(fl[i]), bytes=float(by[i])))
+        return out
 
     def profile_read(self):
         """Stats of the dominant implicit-GEMM kernel (and of all GEMM launches) since the last read."""
@@ -198,14 +267,6 @@ class Engine:
         _lib.check(self.lib.asyrp_profile_read(self.h, C.byref(var), C.byref(ms), C.byref(n), C.byref(fl),
                                                C.byref(by), C.byref(ams), C.byref(afl)))
         v = var.value
-        fam, tid = v // 100000, (v // 1000) % 100
-        ks, stride = (v // 100) % 10, (v // 10) % 10
-        if fam == 1:
-            tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
-                    12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
-            name = "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
-        else:
-            tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
-            name = "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
-        return dict(variant=v, family="f16x3" if fam == 1 else "f32", kernel=name, ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value,
+        fam_name, name = self.variant_name(v)
+        return dict(variant=v, family=fam_name, kernel=name, ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value,
                     all_ms=ams.value, all_flops=afl.value)

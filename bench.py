@@ -8,7 +8,9 @@ Inputs (x0, weights) are resident in HBM before the timed region; synthetic data
 weights of the reference architecture (no checkpoints offline).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+      N > 1 without a launcher: bench.py re-executes itself under torch.distributed.run with N ranks
+      (one process per GPU, RCCL), and fails loudly when fewer than N GPUs are visible.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields); weak scaling: every rank edits its
 own B images with no data-path collective, then the final images are all-gathered once (RCCL).
@@ -16,6 +18,7 @@ own B images with no data-path collective, then the final images are all-gathere
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 from argparse import Namespace
@@ -29,6 +32,7 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, dense matrix peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; f16/bf16 MFMA ~2500 TFLOP/s
 F32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2500.0
+HBM_PEAK_TBS = 8.0
 # measured on this chip with random operands, bare MFMA stream (scripts/calib/mfma_peak.hip -> profiles/r01_calib_mfma_peak.txt):
 # the power envelope caps v_mfma_f32_32x32x16_f16 at 1.66 PFLOP/s (2.46 with zero operands)
 F16_MFMA_MEASURED_RANDOM_TFLOPS = 1657.0
@@ -46,39 +50,117 @@ def celeba_namespace():
                      data=Namespace(image_size=c["resolution"]))
 
 
-def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False):
-    """Oracle (CPU restatement of the reference, kind="port") timed on this host's cores on a bounded sample:
-    B=1, 2 inversion steps + 2 Asyrp steps (dual decoder, as the reference executes them), extrapolated
-    linearly to the 39 + 40 steps of one edit."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1 only): the reference itself when it is importable here, else the oracle (its restatement)
+# ---------------------------------------------------------------------------------------------------------------------
+def _reference_root():
+    ref = os.environ.get("ASYRP_REFERENCE", "/root/reference")
+    return ref if os.path.isfile(os.path.join(ref, "utils", "diffusion_utils.py")) else None
+
+
+def _cpu_step_fn(model_cpu_sd, betas, family, learn_sigma):
+    """(kind, step) with step(x, t, t_next, **kw) -> (xt_next, x0_t, delta_h, middle_h) on the CPU."""
+    import numpy as np
+    ref = _reference_root()
+    if ref:
+        sys.path.insert(0, ref)
+        try:
+            from utils.diffusion_utils import denoising_step as ref_step
+            if family == "ddpm":
+                from models.ddpm.diffusion import DDPM as RefDDPM
+                m = RefDDPM(celeba_namespace())
+            else:
+                from models.improved_ddpm.script_util import i_DDPM as ref_iddpm
+                m = ref_iddpm("AFHQ" if family == "afhq" else "IMAGENET")
+            m.setattr_layers(1)
+            m.load_state_dict(model_cpu_sd, strict=True)
+            m.eval()
+
+            def step(x, t, t_next, **kw):
+                with torch.no_grad():
+                    return ref_step(x, t=t, t_next=t_next, models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim",
+                                    learn_sigma=learn_sigma, **kw)
+            return "reference", step
+        except Exception as e:     # an unimportable reference is not an error of the bench: fall back to the port, say so
+            print(f"[bench] reference at {ref} not usable ({type(e).__name__}: {e}); timing the oracle port", file=sys.stderr)
+        finally:
+            sys.path.remove(ref)
     from oracle import sampler as osamp
     from oracle.weights import DDPMConfig
-    # physical cores visible to this process (torch's default intra-op pool); os.cpu_count() counts SMT siblings
-    cores = max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0))))
-    torch.set_num_threads(cores)
     if family == "ddpm":
         cfg = DDPMConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in CELEBA.items()})
         model = osamp.make_model(model_cpu_sd, cfg)
     else:
         from oracle import iddpm as oi
         model = oi.make_model(model_cpu_sd, oi.AFHQ if family == "afhq" else oi.IMAGENET)
+
+    def step(x, t, t_next, **kw):
+        return osamp.denoising_step(x, t, t_next, model=model, b=betas, learn_sigma=learn_sigma, **kw)
+    return "port", step
+
+
+def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=None):
+    """The reference's own modules (kind="reference") when /root/reference (or $ASYRP_REFERENCE) is importable on this
+    host, else the oracle restatement (kind="port"), timed on a bounded sample: B=1, 4 inversion steps + 4 Asyrp steps
+    (dual decoder, as the reference executes them), extrapolated linearly to the 39 + 40 steps of one edit.
+    Thread count: the best of {16, 32, 64, all} visible cores on one warm forward (128 oversubscribed threads were
+    slower than 8 in round 1).  Also returns the CPU result of the first inversion step on `x_check` for the parity check."""
+    kind, step = _cpu_step_fn(model_cpu_sd, betas, family, learn_sigma)
+    avail = len(os.sched_getaffinity(0))
     g = torch.Generator().manual_seed(1234)
     x = 2 * torch.rand((1, 3, 256, 256), generator=g) - 1
     one = torch.ones(1)
-    ls = dict(learn_sigma=learn_sigma)
-    osamp.denoising_step(x, one * 0.0, one * 25.0, model=model, b=betas, eta=0, **ls)          # warm-up
+    tried = {}
+    step(x, one * 0.0, one * 25.0, eta=0)           # page in / warm caches
+    for n in sorted({min(n, avail) for n in (16, 32, 64, avail)}):
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        step(x, one * 0.0, one * 25.0, eta=0)
+        tried[n] = time.perf_counter() - t0
+    cores = min(tried, key=tried.get)
+    torch.set_num_threads(cores)
+    inv_pairs = ((0, 25), (25, 51), (51, 76), (76, 102))
+    gen_pairs = ((999, 973), (973, 947), (947, 922), (922, 896))
     t0 = time.perf_counter()
-    for (i, j) in ((0, 25), (25, 51)):
-        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0, **ls)
-    t_inv = (time.perf_counter() - t0) / 2
+    for (i, j) in inv_pairs:
+        x, _, _, _ = step(x, one * float(i), one * float(j), eta=0)
+    t_inv = (time.perf_counter() - t0) / len(inv_pairs)
     t0 = time.perf_counter()
-    for (i, j) in ((999, 973), (973, 947)):
-        x, _, _, _ = osamp.denoising_step(x, one * i, one * j, model=model, b=betas, eta=0, index=0, t_edit=T_EDIT,
-                                          hs_coeff=(1.0, 1.0), **ls)
-    t_gen = (time.perf_counter() - t0) / 2
+    for (i, j) in gen_pairs:
+        x, _, _, _ = step(x, one * float(i), one * float(j), eta=0.0, index=0, t_edit=T_EDIT, hs_coeff=(1.0, 1.0))
+    t_gen = (time.perf_counter() - t0) / len(gen_pairs)
     per_image = (N_INV - 1) * t_inv + N_GEN * t_gen
-    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"B=1: 2 inversion + 2 dual-decoder Asyrp steps timed ({t_inv:.2f} s, {t_gen:.2f} s per step), "
-                      f"extrapolated to {N_INV - 1}+{N_GEN} steps"}
+    check = None
+    if x_check is not None:
+        check = step(x_check, one * 0.0, one * 25.0, eta=0)[0]
+    res = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": kind,
+           "sample": f"B=1: {len(inv_pairs)} inversion + {len(gen_pairs)} dual-decoder Asyrp steps timed ({t_inv:.2f} s, "
+                     f"{t_gen:.2f} s per step), extrapolated to {N_INV - 1}+{N_GEN} steps; threads chosen by one warm forward each: "
+                     + ", ".join(f"{n}: {s:.2f} s" for n, s in tried.items()) + f" (host has {avail} visible cores)"}
+    return res, check
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    backend = os.environ.get("ASYRP_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        sys.exit(f"[bench] --gpus {n} requested but only {have} GPU(s) visible: refusing to report a {n}-GPU number")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ASYRP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
 
 
 def main():
@@ -93,17 +175,24 @@ def main():
                          "configs[4] per GPU (ADM, batch 128 = 8 x 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: 3 x f16 MFMA per product, fp32-equivalent (default); f32: fp32-input MFMA")
     a = ap.parse_args()
 
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _self_launch(a.gpus)            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if a.gpus != world:
+        sys.exit(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: they must agree")
     # ASYRP_BENCH_BACKEND=gloo is a DRY-RUN knob for a box with fewer GPUs than ranks (ranks share devices, the final
     # gather is staged through host memory): it exercises the launcher / barrier / max-over-ranks code, not RCCL
     backend = os.environ.get("ASYRP_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        sys.exit(f"[bench] {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one process per GPU)")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -112,8 +201,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))   # RCCL
         else:
             dist.init_process_group(backend=backend)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -134,16 +221,19 @@ def main():
     model = model.to(dev).eval()
     betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
     g = torch.Generator().manual_seed(1234 + rank)
-    x0 = (2 * torch.rand((B, 3, 256, 256), generator=g) - 1).to(dev)
+    x0_cpu = 2 * torch.rand((B, 3, 256, 256), generator=g) - 1
+    x0 = x0_cpu.to(dev)
     eng = model.engine(dev)
     model.set_schedule(betas)
+    edit_kw = dict(n_inv=N_INV, n_gen=N_GEN, t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
+                   learn_sigma=learn_sigma)
 
     def one_step():
-        x_edit = run_edit(model, x0, betas, n_inv=N_INV, n_gen=N_GEN, t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0,
-                          hs_coeff=(1.0, 1.0), learn_sigma=learn_sigma)
+        local = run_edit(model, x0, betas, **edit_kw)
+        full = local
         if world > 1:   # the one collective of the path
-            x_edit = gather_shards(x_edit, B * world) if backend == "nccl" else gather_shards(x_edit.cpu(), B * world).to(dev)
-        return x_edit
+            full = gather_shards(local, B * world) if backend == "nccl" else gather_shards(local.cpu(), B * world).to(dev)
+        return local, full
 
     for _ in range(a.warmup):
         one_step()
@@ -156,20 +246,35 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = one_step()
+        out_local, out = one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = None
+    prof, table = None, []
     if not a.no_kernel_events:
         eng.profile_enable(False)
+        table = eng.profile_table()
         prof = eng.profile_read()
     if world > 1:
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite output"
+    assert out.shape[0] == B * world
+
+    # ---- parity at the benchmarked configuration (outside the timed region) ----------------------------------------
+    # (1) batch invariance: images 0 and B-1 edited ALONE (B=1) must equal their rows of the batched result bit for bit
+    # (2) (N=1, with the CPU baseline) the first inversion step of image 0 inside the full batch vs the CPU reference/oracle
+    parity = None
+    if not a.no_parity_check:
+        diffs = {}
+        for i in sorted({0, B - 1}):
+            alone = run_edit(model, x0[i:i + 1].contiguous(), betas, **edit_kw)
+            diffs[i] = float((alone[0] - out_local[i]).abs().max())
+        parity = {"batch_invariance_bitwise": all(v == 0.0 for v in diffs.values()),
+                  "images_checked_alone_vs_in_batch": sorted(diffs), "max_abs_diff": max(diffs.values()),
+                  "what": f"run_edit of image i alone (B=1) == row i of the B={B} x_edit, full {N_INV - 1}+{N_GEN} steps"}
 
     # seconds per step of the two loops separately, outside the timed region: 3 fused steps of each kind
     def phase_ms(t, t_next, **kw):
@@ -182,7 +287,9 @@ def main():
     phases = {"inversion_step": phase_ms(486, 512),
               "generation_step_t>=t_edit(dual decoder)": phase_ms(742, 717, index=0, apply_edit=True, hs_coeff=(1.0, 1.0)),
               "generation_step_t<t_edit": phase_ms(256, 230, index=0, apply_edit=False, hs_coeff=(1.0, 1.0))}
+    first_step_gpu = eng.ddim_step(x0, 0, 25, learn_sigma=learn_sigma)[0][0:1].cpu() if rank == 0 else None
 
+    rc = 0
     if rank == 0:
         images = B * world * a.steps
         res = {
@@ -195,7 +302,10 @@ def main():
                                     "imagenet": "ImageNet ADM (improved_ddpm UNet, 256 base ch)"}[a.config] +
                                    f" 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
                                    f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
-                       "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)"},
+                       "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)",
+                       "launcher": "self (bench.py re-executed under torch.distributed.run)"
+                       if os.environ.get("ASYRP_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
+                       "collective_backend": (backend if world > 1 else None)},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
             "generation_only_images_per_s": B * world / (1e-3 * (20 * phases["generation_step_t>=t_edit(dual decoder)"] +
@@ -203,7 +313,7 @@ def main():
         }
         if prof and prof["launches"]:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
-            if prof["family"] == "f16x3":
+            if prof["family"] in ("f16x3", "attention"):
                 # the kernel issues 3 f16 matrix products per algorithmic (fp32-equivalent) product: its ceiling for
                 # ALGORITHMIC flops is the dense f16 MFMA peak / 3
                 peak = F16_MFMA_PEAK_TFLOPS / 3.0
@@ -221,21 +331,61 @@ def main():
                                                                  if prof["family"] == "f16x3" else None),
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
+        # per-kernel-family table (both bounds, the binding one named per family), from the same HIP-event record
+        fams = []
+        for r in sorted(table, key=lambda r: -r["ms"]):
+            if not r["launches"] or r["ms"] <= 0:
+                continue
+            mf_peak = F32_MFMA_PEAK_TFLOPS if r["family"] == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
+            t_mfma = r["flops"] / (mf_peak * 1e12)
+            t_hbm = r["bytes"] / (HBM_PEAK_TBS * 1e12)
+            sec = r["ms"] * 1e-3
+            fams.append({"kernel": r["kernel"], "launches_per_step": r["launches"] / a.steps,
+                         "share_of_step": sec / dt, "tflops": r["flops"] / sec / 1e12, "algorithmic_GBps": r["bytes"] / sec / 1e9,
+                         "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac_of_bound": max(t_mfma, t_hbm) / sec})
+        if fams:
+            res["kernel_families"] = fams
+            att = [r for r in table if r["family"] == "attention" and r["ms"] > 0]
+            if att:
+                ms_, fl_ = sum(r["ms"] for r in att), sum(r["flops"] for r in att)
+                res["roofline_attention"] = {"bound": "mfma", "achieved": fl_ / (ms_ * 1e-3) / 1e12,
+                                             "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                             "frac": fl_ / (ms_ * 1e-3) / 1e12 / (F16_MFMA_PEAK_TFLOPS / 3.0),
+                                             "f16_mfma_issue_tflops": 3.0 * fl_ / (ms_ * 1e-3) / 1e12,
+                                             "launches_per_step": sum(r["launches"] for r in att) / a.steps,
+                                             "share_of_step": ms_ * 1e-3 / dt,
+                                             "kernels": sorted({r["kernel"] for r in att})}
         # HBM traffic of the dominant kernel: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of
         # this same command (scripts/gpu_traffic.sh -> profiles/traffic_main_tile.json) are reported per launch
         tpath = os.path.join(ROOT, "profiles", "traffic_main_tile.json")
         if "roofline" in res and a.config == "celeba" and B == 32 and os.path.exists(tpath):
             tr = json.load(open(tpath))
             if tr.get("kernel") == res["roofline"]["kernel"]:
-                res["roofline"]["traffic"] = 1024.0 * (2.0 * tr["FETCH_SIZE_KB_per_launch"] + tr["WRITE_SIZE_KB_per_launch"])
-                res["roofline"]["traffic_note"] = ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC passes "
-                                                   f"({tr['round']}); x2 = gfx950 FETCH_SIZE correction; compare with "
-                                                   "algorithmic_bytes_per_launch")
+                res["roofline"]["traffic"] = 1024.0 * (tr.get("fetch_scale", 2.0) * tr["FETCH_SIZE_KB_per_launch"] +
+                                                       tr.get("write_scale", 1.0) * tr["WRITE_SIZE_KB_per_launch"])
+                res["roofline"]["traffic_note"] = tr.get("note", "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) from the "
+                                                         f"committed PMC passes ({tr['round']}); compare with algorithmic_bytes_per_launch")
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, betas, family, learn_sigma)
+            res["cpu_baseline"], cpu_first = cpu_baseline(cpu_sd, betas, family, learn_sigma, x_check=x0_cpu[0:1])
+            if parity is not None and cpu_first is not None:
+                err = (first_step_gpu - cpu_first).abs()
+                ok = bool((err <= 1e-4 + 1e-3 * cpu_first.abs()).all())
+                parity["first_step_vs_cpu_" + res["cpu_baseline"]["kind"]] = {
+                    "what": f"xt_next of inversion step t=0->25, image 0 computed inside the B={B} batch on the GPU vs the CPU "
+                            f"{res['cpu_baseline']['kind']} on the same x0", "within_rtol1e-3_atol1e-4": ok,
+                    "max_abs_err": float(err.max()), "mean_abs_err": float(err.mean())}
+                if not ok:
+                    rc = 1
+        if parity is not None:
+            res["parity_check"] = parity
+            if not parity["batch_invariance_bitwise"]:
+                rc = 1
         print(json.dumps(res), flush=True)
+        if rc:
+            print("[bench] PARITY CHECK FAILED (see parity_check in the JSON line)", file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

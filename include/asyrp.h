@@ -76,7 +76,7 @@ typedef struct asyrp_config {
 typedef struct asyrp_engine asyrp_engine;
 
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
-#define ASYRP_ABI_VERSION 3
+#define ASYRP_ABI_VERSION 4
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */
@@ -154,6 +154,19 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
                    const float* hs_coeff_host, int n_coeff, int learn_sigma, const float* noise, int n_noise,
                    float* x_T, float* x_edit, void* stream);
 
+/* Loop A alone with a per-step read-out: DDIM inversion over seq_inv (n_inv - 1 steps, step k = 0..n_inv-2 takes
+ * t = seq_inv[k] -> t_next = seq_inv[k+1]).  For the steps k in [tap_first, tap_first + tap_count) the step's outputs are
+ * copied out: x_tap[k - tap_first] = x_{t_next} and x0t_tap[k - tap_first] = x0_t, each [B,3,R,R] (either buffer may be
+ * null).  x_last (nullable) receives the final latent.  This is the engine half of the reference's LPIPS(t) table
+ * builder, which feeds x and x0_t of every one of its (up to 1000) inversion steps to LPIPS
+ * (diffusion_latent.py:1239-1276); callers walk a long inversion in windows by restarting from the last tap. */
+int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv_host, int n_inv, int learn_sigma,
+                        int tap_first, int tap_count, float* x_tap, float* x0t_tap, float* x_last, void* stream);
+
+/* DDPM.get_temb (models/ddpm/diffusion.py:464-470): t [B] float timesteps (device) -> temb [B, 4*ch] (device).
+ * For the iDDPM family: time_embed(timestep_embedding(t)) (models/improved_ddpm/unet.py:688). */
+int asyrp_get_temb(asyrp_engine* e, const float* t, int B, float* temb_out, void* stream);
+
 /* Bytes of device memory held by the engine (weights + workspace). */
 int64_t asyrp_device_bytes(const asyrp_engine* e);
 
@@ -172,6 +185,11 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  * Resets the record. */
 int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launches, double* flops, double* bytes,
                        double* all_ms, double* all_flops);
+
+/* Per-kernel-family rows of the same record (variant ids as above; 200000 + T = the fused attention kernel over T tokens
+ * with flops = 4*T*T*C per image).  Does not reset the record.  Returns the number of rows written, negative on error. */
+int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms, int64_t* launches, double* flops,
+                        double* bytes);
 
 /* ---- op-level test hooks (tests/ only; same kernels the engine launches) ---------------------- */
 /* y = conv2d(act(x)) [+bias] [+ per-image channel vector] [+ residual], NCHW fp32 in and out.

@@ -277,6 +277,96 @@ def run_slerp(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def _seq40():
+    seq = [int(s + 1e-6) for s in list(np.linspace(0, 1, 40) * 999)]      # diffusion_latent.py:955-957
+    return seq, [-1] + seq[:-1]
+
+
+def config1_state_dict(tame=1.0):
+    """BASELINE.json configs[0]/[1]: CelebA-HQ DDPM with hash base weights (seed 1234) + the SHIPPED `smiling` DeltaBlock
+    (checkpoint/smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth["0"], loaded as diffusion_latent.py:674-676 does)."""
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    ck = torch.load(os.path.join(REF, "checkpoint", "smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth"), map_location="cpu",
+                    weights_only=False)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    if tame != 1.0:   # see run_config1
+        sd["conv_out.weight"] = sd["conv_out.weight"] * tame
+        sd["conv_out.bias"] = sd["conv_out.bias"] * tame
+    return sd
+
+
+def run_config1(out, tame=1.0):
+    """BASELINE config 1 end to end through the REFERENCE: B=1, full 39 inversion + 40 Asyrp steps, t_edit=500, once with
+    t_addnoise=0 and once with t_addnoise=167 consuming stored noise (randn(7,1,3,256,256), manual_seed(4321)).
+    Stored: x_T, both x_edit, and (x_t, xt_next, x0_t, delta_h) at chosen steps for teacher-forced GPU parity at full size:
+    first / last inversion step, first and last edited generation step (t >= t_edit), first un-edited step, the
+    t_next = -1 step, two eta = 1 steps.  x_t of a step is stored only where it is not another stored tensor."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd = config1_state_dict(tame)
+    m = ref_model(CELEBA, sd, n_delta=1)
+    x0 = hash_uniform("config1.x0", (1, 3, 256, 256), seed=1234)          # an image in [-1, 1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    seq, seq_next = _seq40()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim")
+    one = torch.ones(1)
+    g = {}
+    with torch.no_grad():
+        x = x0.clone()
+        for k, (i, j) in enumerate(zip(seq_next[1:], seq[1:])):
+            xin = x
+            x, x0t, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0, **kw)
+            if k == 0:
+                g["inv_first.xt_next"], g["inv_first.x0_t"] = x.clone(), x0t.clone()
+            if k == len(seq) - 2:
+                g["inv_last.x_t"], g["inv_last.x0_t"] = xin.clone(), x0t.clone()
+        g["x_T"] = x.clone()
+        ek = dict(index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        torch.manual_seed(4321)
+        noise = torch.randn(7, 1, 3, 256, 256)
+        xs = None
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            xin = x
+            x, x0t, dh, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, **ek, **kw)
+            if i == 999:
+                g["gen999.xt_next"], g["gen999.x0_t"], g["gen999.delta_h"] = x.clone(), x0t.clone(), dh.clone()
+            if i == 512:
+                g["gen512.x_t"], g["gen512.xt_next"], g["gen512.x0_t"] = xin.clone(), x.clone(), x0t.clone()
+                g["gen512.delta_h"] = dh.clone()
+            if i == 486:      # first step below t_edit: x_t == gen512.xt_next
+                assert dh is None
+                g["gen486.xt_next"] = x.clone()
+            if i == 179:
+                xs = x.clone()            # state entering the eta = 1 tail (t = 153 < 167)
+            if i == 0:
+                g["gen0.x_t"] = xin.clone()
+        g["x_edit"] = x.clone()           # == x0_t of the last step (alpha_bar_next = 1)
+        # the same generation with the stochastic tail: identical until t = 179, then eta = 1 with the stored noise
+        x, k = xs, 0
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            if i >= 167:
+                continue
+            xin = x
+            torch.manual_seed(0)          # randn_like is replaced below: feed the stored noise through the reference
+            z = noise[k]
+            k += 1
+            _orig = torch.randn_like
+            torch.randn_like = lambda t, _z=z: _z.clone()
+            try:
+                x, x0t, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=1.0, **ek, **kw)
+            finally:
+                torch.randn_like = _orig
+            if i == 153:
+                g["eta153.x_t"], g["eta153.xt_next"], g["eta153.x0_t"] = xin.clone(), x.clone(), x0t.clone()
+            if i == 0:
+                g["eta0.x_t"] = xin.clone()
+        assert k == 7
+        g["x_edit_noise"] = x.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -290,7 +380,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config3"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))

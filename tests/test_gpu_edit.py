@@ -178,3 +178,32 @@ def test_precompute_pairs_and_strength_sweep(small, tmp_path):
         st = err_stats(got, want)
         print(hc, st)
         assert st["max_abs"] <= 1e-4 * max(1.0, st["ref_absmax"]) and st["frac_outside"] <= 0.02
+
+
+def test_inversion_with_per_step_taps(small):
+    """asyrp_run_inversion (engine half of the LPIPS(t) builder, diffusion_latent.py:1239-1276): x and x0_t of every
+    inversion step equal the chain of fused steps bit for bit; a tap window in the middle returns the same rows."""
+    from asyrp_official_amd import cache
+    m, _, x = small
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    eng = m._ready_engine(x.cuda())
+    seq = osamp.timestep_seq(10)[0]
+    xs, x0s = [], []
+    cur = x.cuda()
+    for i, j in zip(seq[:-1], seq[1:]):
+        cur, x0t, _, _ = eng.ddim_step(cur, i, j)
+        xs.append(cur)
+        x0s.append(x0t)
+    x_last, x_tap, x0t_tap = eng.run_inversion(x.cuda(), seq, tap_first=0, tap_count=len(seq) - 1)
+    assert torch.equal(x_last, xs[-1])
+    assert torch.equal(x_tap, torch.stack(xs)) and torch.equal(x0t_tap, torch.stack(x0s))
+    _, x_mid, _ = eng.run_inversion(x.cuda(), seq, tap_first=3, tap_count=2, want_x0t=False)
+    assert torch.equal(x_mid, torch.stack(xs[3:5]))
+    with pytest.raises(Exception):
+        eng.run_inversion(x.cuda(), seq, tap_first=8, tap_count=5)
+    # the host-side walk in windows (bounded memory for n_inv = 1000) yields the same per-step pairs
+    got = list(cache.inversion_trace(m, x.cuda(), b, n_inv=10, window=4))
+    assert [j for j, _, _ in got] == seq[1:]
+    for (j, gx, gx0), wx, wx0 in zip(got, xs, x0s):
+        assert torch.equal(gx, wx) and torch.equal(gx0, wx0)

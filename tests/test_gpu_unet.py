@@ -89,3 +89,82 @@ def test_celeba_full_size_forward(golden_celeba, conv_math):
     assert_close(et, o_et, what="oracle et")
     assert_close(em, o_em, what="oracle et_mod")
     assert_close(mh, o_mh, what="oracle middle_h")
+
+
+def test_full_size_batch_invariance_bitwise():
+    """256x256 CelebA-HQ UNet: image 1 alone (B=1) == image 1 inside a batch of 2, bit for bit, for the dual forward.
+    The tile / fused-shortcut / GroupNorm-partial decisions are functions of the layer shape only (never of the batch),
+    so sharding a batch over ranks cannot change an image (the choice used to flip between B=1 and B>=2)."""
+    sd = synthetic(CELEBA, 1, seed=1234)
+    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    x = torch.cat([hash_normal("celeba.x", (1, 3, 256, 256), seed=1234), hash_normal("celeba.x2", (1, 3, 256, 256), seed=5)])
+    xc = x.cuda()
+    t2, t1 = torch.ones(2, device="cuda") * 768.0, torch.ones(1, device="cuda") * 768.0
+    et2, em2, dh2, mh2 = m(xc, t2, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    for i in (0, 1):
+        et1, em1, dh1, mh1 = m(xc[i:i + 1].contiguous(), t1, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        assert torch.equal(et2[i:i + 1], et1) and torch.equal(em2[i:i + 1], em1)
+        assert torch.equal(dh2[i:i + 1], dh1) and torch.equal(mh2[i:i + 1], mh1)
+
+
+def test_get_temb(small):
+    """DDPM.get_temb (models/ddpm/diffusion.py:464-470) on the engine vs the oracle's restatement."""
+    from oracle.ddpm import temb_mlp
+    m, sd, _ = small
+    t = torch.tensor([701.0, 25.0])
+    got = m.get_temb(t.cuda())
+    want = temb_mlp(sd, t, SMALL.ch)
+    assert got.shape == want.shape == (2, SMALL.ch * 4)
+    assert_close(got, want, what="temb")
+
+
+def test_delta_block_reload_repacks_only_what_changed(small):
+    """Loading another DeltaBlock (checkpoint/*.pth["0"] flow, diffusion_latent.py:674-676) re-uploads the dirty tensors
+    only; the result equals a freshly built model with the same parameters."""
+    m, sd, x = small
+    sd2 = dict(sd)
+    for k in list(sd2):
+        if k.startswith("layer_0."):
+            sd2[k] = sd[k] * 1.5 + 0.01
+    t = torch.ones(2, device="cuda") * 701.0
+    m.layer_0.load_state_dict({k[len("layer_0."):]: v for k, v in sd2.items() if k.startswith("layer_0.")})
+    got = m(x.cuda(), t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    fresh = hip_model(SMALL, sd2, 2, conv_math=m.conv_math)
+    want = fresh(x.cuda(), t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+    m.load_state_dict(sd)        # restore for the other tests of this module
+    back = m(x.cuda(), t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    o_et, o_em, _, _ = ddpm_forward(sd, SMALL, x, t.cpu(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    assert_close(back[1], o_em, what="et_mod after restoring the DeltaBlock")
+
+
+def test_stream_switch_is_ordered(small):
+    """Two calls on different streams: the engine orders workspace reuse behind the previous stream's work."""
+    m, _, x = small
+    xc = x.cuda()
+    t = torch.ones(2, device="cuda") * 701.0
+    ref = m(xc, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(4):
+        if k % 2:
+            with torch.cuda.stream(side):
+                outs.append(m(xc, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0)))
+        else:
+            outs.append(m(xc, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0)))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])
+
+
+def test_wrong_shapes_fail_loudly(small):
+    m, _, x = small
+    eng = m._ready_engine(x.cuda())
+    with pytest.raises(ValueError):
+        eng.ddim_step(torch.zeros(2, 3, 16, 16, device="cuda"), 10, 5)
+    with pytest.raises(ValueError):
+        eng.ddim_step(x.cuda(), 25, 0, eta=1.0, noise=torch.zeros(2, 3, 32, 16, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.run_edit(x.cuda(), [0, 999], [0, 999], t_edit=500, t_addnoise=600, noise=torch.zeros(2, 3, 32, 32, device="cuda"))
