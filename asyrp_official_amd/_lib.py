@@ -27,7 +27,7 @@ class AsyrpConfig(C.Structure):
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
-ABI_VERSION = 4   # include/asyrp.h ASYRP_ABI_VERSION
+ABI_VERSION = 5   # include/asyrp.h ASYRP_ABI_VERSION
 
 _SIGS = {
     "asyrp_abi_version": (C.c_int, []),
@@ -56,7 +56,7 @@ _SIGS = {
     "asyrp_op_conv2d_stats": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     "asyrp_op_resblock_tail": (C.c_int, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P, _P]),
     "asyrp_op_conv_bench": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P]),
-    "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _I, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libasyrp_hip.so")
-SOURCES = ["kernels.hip", "conv_f16x3.hip", "engine.hip"]
+SOURCES = ["kernels.hip", "conv_f16x3.hip", "attention.hip", "engine.hip"]
 DEPS = SOURCES + ["kernels.h", os.path.join("..", "..", "include", "asyrp.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-comment"]
 
@@ -27,10 +27,31 @@ def needs_build():
 
 
 def build_library(force=False, verbose=True):
-    """Compile the HIP sources into asyrp_official_amd/libasyrp_hip.so; returns the path."""
+    """Compile the HIP sources into asyrp_official_amd/libasyrp_hip.so; returns the path.
+    One hipcc -c per source, run concurrently (objects under csrc/build/, git-ignored), then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, d)) for d in DEPS if not d.endswith(".hip"))
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_t):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", srcp, "-o", obj]
+        if verbose:
+            print("[asyrp build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print("[asyrp build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

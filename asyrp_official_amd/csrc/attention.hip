@@ -1,0 +1,286 @@
+// attention.hip — fused self-attention on the f16 matrix cores (gfx950), fp32-equivalent through the same two-term
+// operand split as conv_f16x3.hip:  out = softmax(Q K^T * scale) V  per (image, head), no T x T tensor in HBM.
+//
+// Reference ops replaced: models/ddpm/diffusion.py:205-221 (AttnBlock: bmm(q,k)*C^-0.5, softmax, bmm(v,w^T)) and
+// models/improved_ddpm/unet.py:379-396 (QKVAttentionLegacy: heads of 64 channels, softmax in fp32).
+//
+// One workgroup = 32 queries of one (image, head); its 4 waves split the KEYS (wave w owns keys [w*NKT*32, (w+1)*NKT*32)).
+//   S^T = K Q^T   v_mfma_f32_32x32x16_f16, A = K rows (loaded global -> registers, 32 contiguous bytes per lane per K-step,
+//                 split into f16 hi/lo in registers), B = Q (staged once per workgroup into LDS as hi/lo f16);
+//                 three products per K-step: k_lo*q_hi + k_hi*q_hi + k_hi*q_lo (fp32 accumulate).
+//                 The transposed product leaves, in the accumulator layout, each lane holding ITS query (lane&31) against
+//                 16 keys per tile -- exactly the A-operand layout of the second product, so P never goes through LDS.
+//   softmax       row max / row sum: in-register over the wave's keys, lane^32 shuffle, then a 4-wave exchange through
+//                 LDS (2 barriers); p = exp(s - max) / sum as the reference's softmax-then-matmul order.
+//   O = P V       A = P (registers, hi/lo split of p * 2^10: keeps p_lo a normal f16), B = V gathered global -> registers
+//                 in the key order the accumulator layout dictates (8 dword loads per lane per 16 keys), same 3 products;
+//                 every wave produces a partial O over its keys, the 4 partials are added in a fixed order through LDS
+//                 (deterministic) and stored coalesced along the channel axis.
+// Single pass over the keys (T <= 1024: the whole score row of a query lives in the 4 waves' registers), so no online
+// rescaling is needed.  Larger T / head widths fall back to the unfused path in engine.hip.
+#include "kernels.h"
+
+namespace asyrp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float P_SCALE = 1024.0f;            // power of two: exact; undone on the output
+constexpr float P_UNSCALE = 1.0f / 1024.0f;
+constexpr float AH_MAX = 65504.0f;
+
+__device__ __forceinline__ void asplit8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 s;
+    s[0] = __builtin_amdgcn_fmed3f(v[j], -AH_MAX, AH_MAX);
+    s[1] = __builtin_amdgcn_fmed3f(v[j + 1], -AH_MAX, AH_MAX);
+    const h2 h = __builtin_convertvector(s, h2);
+    f2 r;
+    r[0] = s[0] - (float)h[0];
+    r[1] = s[1] - (float)h[1];
+    const h2 l = __builtin_convertvector(r, h2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
+
+// NKT = 32-key tiles per wave (T <= NKT*128); DCH = 32-channel output tiles accumulated per pass over the keys
+template <int NKT, int DCH>
+__global__ void __launch_bounds__(256, 1) attn_f16x3_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T, Dh = p.Dh, ld = p.ld;
+  const int q0 = blockIdx.x * 32;
+  const float* __restrict__ base = p.qkv + (long long)blockIdx.z * p.img_stride + (long long)blockIdx.y * p.head_stride;
+  const float* __restrict__ Q = base + p.q_off;
+  const float* __restrict__ K = base + p.k_off;
+  const float* __restrict__ V = base + p.v_off;
+  const int nks = Dh >> 4;                         // K-steps of 16 channels
+
+  // LDS: Qs [nks][4 units: hi h0, hi h1, lo h0, lo h1][32 queries][8 halfs]  |  red [2][4 waves][32]  |  Os [4][32][DCH*32] f32
+  char* const Qs = smem;
+  float* const red = reinterpret_cast<float*>(smem + (size_t)nks * 4 * 32 * 16);
+  float* const Os = red + 2 * 4 * 32;
+
+  // ---- stage Q (hi/lo) ----
+  for (int idx = tid; idx < 32 * (Dh >> 3); idx += 256) {
+    const int q = idx & 31, oct = idx >> 5;
+    const int row = min(q0 + q, T - 1);
+    const float* src = Q + (long long)row * ld + oct * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    h8 hi, lo;
+    asplit8(v, hi, lo);
+    const int ks = oct >> 1, hh = oct & 1;
+    *reinterpret_cast<h8*>(Qs + ((size_t)(ks * 4 + hh) * 32 + q) * 16) = hi;
+    *reinterpret_cast<h8*>(Qs + ((size_t)(ks * 4 + 2 + hh) * 32 + q) * 16) = lo;
+  }
+  __syncthreads();
+
+  // ---- S^T = K Q^T over this wave's keys ----
+  const int kbase = wave * NKT * 32;
+  f32x16 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+  int koff[NKT];                                   // 32-bit element offsets: a (image, head) slab is far below 2^31 floats
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) koff[kt] = min(kbase + kt * 32 + c, T - 1) * ld + 8 * h;
+  const bool wave_has_keys = (kbase < T);
+  if (wave_has_keys) {
+    // software pipeline over the K-steps: a ring of RK register sets keeps the K rows of the next RK steps in flight while a
+    // step feeds the matrix cores (one wave per SIMD: nothing else hides the L2 latency)
+    constexpr int RK = (NKT >= 8) ? 2 : (8 / NKT > 8 ? 8 : 8 / NKT);
+    float4 ka[RK][NKT], kb[RK][NKT];
+    auto loadK = [&](int ks, int buf) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        ka[buf][kt] = *reinterpret_cast<const float4*>(K + koff[kt] + ks * 16);
+        kb[buf][kt] = *reinterpret_cast<const float4*>(K + koff[kt] + ks * 16 + 4);
+      }
+    };
+    auto stepK = [&](int ks, int buf) {
+      const h8 qh = *reinterpret_cast<const h8*>(Qs + ((size_t)(ks * 4 + h) * 32 + c) * 16);
+      const h8 ql = *reinterpret_cast<const h8*>(Qs + ((size_t)(ks * 4 + 2 + h) * 32 + c) * 16);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const float v[8] = {ka[buf][kt].x, ka[buf][kt].y, ka[buf][kt].z, ka[buf][kt].w,
+                            kb[buf][kt].x, kb[buf][kt].y, kb[buf][kt].z, kb[buf][kt].w};
+        h8 khi, klo;
+        asplit8(v, khi, klo);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qh, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qh, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, ql, s[kt], 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < RK; ++i)
+      if (i < nks) loadK(i, i);
+    for (int ks0 = 0; ks0 < nks; ks0 += RK) {
+#pragma unroll
+      for (int i = 0; i < RK; ++i) {
+        const int ks = ks0 + i;
+        if (ks < nks) {
+          stepK(ks, i);
+          if (ks + RK < nks) loadK(ks + RK, i);
+        }
+      }
+    }
+  }
+
+  // ---- softmax over the keys of query (q0 + c): accumulator element r of tile kt is key kbase + kt*32 + (r&3) + 8*(r>>2) + 4*h ----
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = (key < T) ? s[kt][r] * p.scale : -INFINITY;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (h == 0) red[wave * 32 + c] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[c], red[32 + c]), fmaxf(red[64 + c], red[96 + c]));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(s[kt][r] - mx);       // exp(-inf) = 0 for masked keys
+      s[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  if (h == 0) red[128 + wave * 32 + c] = sum;
+  __syncthreads();
+  sum = (red[128 + c] + red[160 + c]) + (red[192 + c] + red[224 + c]);
+  const float inv_scale = P_SCALE;
+  h8 phi[NKT][2], plo[NKT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __fdiv_rn(s[kt][k2 * 8 + j], sum) * inv_scale;
+      asplit8(v, phi[kt][k2], plo[kt][k2]);
+    }
+
+  // ---- O = P V, DCH output tiles per pass; partials of the 4 waves reduced through LDS ----
+  const int ndt = (Dh + 31) >> 5;
+  float* __restrict__ outz = p.out + (long long)blockIdx.z * p.o_img_stride + (long long)blockIdx.y * p.o_head_stride;
+  for (int d0 = 0; d0 < ndt; d0 += DCH) {
+    f32x16 o[DCH];
+#pragma unroll
+    for (int dt = 0; dt < DCH; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    if (wave_has_keys) {
+      // the (key tile, 16-key step) loop is fully unrolled (P lives in registers); the V gather of step i+1 is issued
+      // before the products of step i.  Addresses are clamped, never predicated: one exec mask for the whole kernel.
+      int dcol[DCH];
+      bool dok[DCH];
+#pragma unroll
+      for (int dt = 0; dt < DCH; ++dt) {
+        const int d = (d0 + dt) * 32 + c;
+        dok[dt] = d < Dh;
+        dcol[dt] = min(d, Dh - 1);
+      }
+      constexpr int NSTEP = NKT * 2;
+      constexpr int RV = (NSTEP < 4) ? NSTEP : ((NKT >= 8) ? 2 : 4);      // V gathers in flight ahead of the products
+      float vb[RV][DCH][8];
+      auto loadV = [&](int step, int buf) {
+        const int kb0 = kbase + step * 16 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ro = min(kb0 + (j & 3) + 8 * (j >> 2), T - 1) * ld;
+#pragma unroll
+          for (int dt = 0; dt < DCH; ++dt) vb[buf][dt][j] = V[ro + dcol[dt]];
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < RV - 1; ++i) loadV(i, i);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + RV - 1 < NSTEP) loadV(st + RV - 1, (st + RV - 1) % RV);
+        const int kt = st >> 1, k2 = st & 1;
+#pragma unroll
+        for (int dt = 0; dt < DCH; ++dt) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = dok[dt] ? vb[st % RV][dt][j] : 0.f;
+          h8 vhi, vlo;
+          asplit8(v, vhi, vlo);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(plo[kt][k2], vhi, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[kt][k2], vhi, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[kt][k2], vlo, o[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // accumulator layout: column = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*h (query)
+    float* ow = Os + (size_t)wave * 32 * DCH * 32;
+#pragma unroll
+    for (int dt = 0; dt < DCH; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * h;
+        ow[(q * DCH + dt) * 32 + c] = o[dt][r];
+      }
+    __syncthreads();
+    for (int e = tid; e < 32 * DCH * 32; e += 256) {
+      const int q = e / (DCH * 32), dl = e - q * (DCH * 32);
+      const int d = d0 * 32 + dl;
+      const float v = ((Os[e] + Os[32 * DCH * 32 + e]) + (Os[2 * 32 * DCH * 32 + e] + Os[3 * 32 * DCH * 32 + e])) * P_UNSCALE;
+      if (q0 + q < T && d < Dh) outz[(long long)(q0 + q) * p.ldo + d] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <int NKT, int DCH>
+static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)(a.Dh >> 4) * 4 * 32 * 16 + 2 * 4 * 32 * sizeof(float) + (size_t)4 * 32 * DCH * 32 * sizeof(float);
+  static bool attr_set[16] = {};
+  if (smem > 64 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<NKT, DCH>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+  }
+  dim3 grid((a.T + 31) / 32, a.heads, a.B);
+  hipLaunchKernelGGL((attn_f16x3_kernel<NKT, DCH>), grid, dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+bool attn_fused_supported(int T, int Dh, int ld, int ldo) {
+  // whole score row in registers: T <= 1024; K-steps of 16 channels; Q image (Dh * 128 B) + output exchange fit the 160 KB LDS;
+  // rows are read as float4
+  return T >= 1 && T <= 1024 && Dh >= 16 && Dh <= 512 && (Dh & 15) == 0 && (ld & 3) == 0 && ldo > 0;
+}
+
+hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s) {
+  if (!attn_fused_supported(a.T, a.Dh, a.ld, a.ldo)) return hipErrorInvalidValue;
+  if ((((uintptr_t)a.qkv) & 15) || ((a.q_off | a.k_off | a.v_off) & 3) || (a.head_stride & 3) || (a.img_stride & 3))
+    return hipErrorInvalidValue;
+  const int nkt = (a.T + 127) / 128;
+  const bool wide = a.Dh > 64;     // 4 output tiles (128 channels) per pass for wide heads, 2 for the 64-channel heads
+  if (nkt <= 1) return wide ? launch_attn<1, 4>(a, s) : launch_attn<1, 2>(a, s);
+  if (nkt <= 2) return wide ? launch_attn<2, 4>(a, s) : launch_attn<2, 2>(a, s);
+  if (nkt <= 4) return wide ? launch_attn<4, 4>(a, s) : launch_attn<4, 2>(a, s);
+  return wide ? launch_attn<8, 4>(a, s) : launch_attn<8, 2>(a, s);
+}
+
+}  // namespace asyrp

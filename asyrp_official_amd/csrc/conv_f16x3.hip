@@ -145,12 +145,18 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   const int ks_id = blockIdx.y % sk;
   const int n0 = (blockIdx.y / sk) * BN;
   const int HWo = p.Hout * p.Wout;
+  // M-tile of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin by linear block id, so with the identity map
+  // the tiles resident on one XCD (one L2) are 8 apart and never share a halo row.  xmap: XCD k takes the contiguous band
+  // [k*gx/8, (k+1)*gx/8) of tiles instead, neighbours meet in the same L2 (only the block -> tile assignment changes: every
+  // tile is computed exactly as before and the statistics rows are indexed by the TILE, so results are bit-identical).
+  int bx = blockIdx.x;
+  if (p.xmap) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);
   int m0 = 0, oy0 = 0, ox0 = 0;
   if (KS == 1) {
-    m0 = blockIdx.x * BM;
+    m0 = bx * BM;
   } else {
     const int tiles_x = (p.Wout + PW - 1) / PW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
     oy0 = ty * T::PH;
     ox0 = tx * PW;
   }
@@ -704,7 +710,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
           s1 += red[((size_t)w * BN + c) * 2];
           s2 += red[((size_t)w * BN + c) * 2 + 1];
         }
-        double* dst = p.stats + (((size_t)zo * gridDim.x + blockIdx.x) * Cout + n0 + c) * 2;
+        double* dst = p.stats + (((size_t)zo * gridDim.x + bx) * Cout + n0 + c) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -715,6 +721,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 static bool is_vec(const GemmArgs& a) {
   return (((a.c0 | a.c1 | a.lda0 | a.lda1 | a.Cin) & 15) == 0) && ((((uintptr_t)a.a0) | ((uintptr_t)a.a1)) & 15) == 0 &&
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
+}
+
+// A/B switch of the XCD-aware tile map (ASYRP_XCD_MAP=0 disables it)
+static bool xcd_map_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_XCD_MAP"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
@@ -732,6 +744,8 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
     gy *= a.sk;
   }
   dim3 grid(gx, gy, a.Z), block(T::NT);
+  GemmArgs ax = a;
+  ax.xmap = (xcd_map_enabled() && gx >= 16 && (gx & 7) == 0 && (gy * (long long)gx) % 8 == 0) ? 1 : 0;
   // per-device (the attribute lives in the device's code object); set once per process and device, under a lock-free
   // idempotent flag: two threads racing here both set the same value
   static bool attr_set[16] = {};
@@ -745,14 +759,18 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
       if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, a);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
 // the 256x128 tile the big 3x3 layers run on: 8 waves (4 per SIMD with two workgroups per CU), plain per-tap loop.
 // Interleaved A/B against the 4-wave software-pipelined tile: +6...12 % per layer, +5 % on the whole edit
 // (profiles/r01_conv_microbench_w8*.txt)
-int gemm_main_tile() { return XT_256x128W8; }
+int gemm_main_tile() {
+  // ASYRP_MAIN_TILE=7 selects the 16-wave 512x128 experiment (A/B only)
+  static const int t = [] { const char* e = getenv("ASYRP_MAIN_TILE"); return (e && atoi(e) == XT_512x128W16) ? XT_512x128W16 : XT_256x128W8; }();
+  return t;
+}
 
 // tile ids of the f16x3 family (GemmArgs.tile / profile variant).
 // The choice is a function of the LAYER SHAPE only: the workgroup count is priced at a nominal batch, never at the
@@ -793,7 +811,7 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = requested_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32 || t == XT_512x128W16) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -803,7 +821,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_512x128W16);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
@@ -811,6 +829,7 @@ int gemm_mblocks(const GemmArgs& a) {
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x32:
       bm = 256; break;
+    case XT_512x128W16: bm = 512; break;
     case XT_128x128: bm = 128; break;
     default: bm = 64;
   }
@@ -832,6 +851,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 3, 3>;      // 49 KB
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
+  using X512x128w16_3 = XCfg<8, 2, 2, 2, 3, 1>;      // experiment: 16 waves share one weight slice and one barrier domain
   using X256x32_3 = XCfg<4, 1, 2, 1, 3, 1, 2, 1>;     // conv_out (Cout = 3 / 6): 32-wide N tile, 6 MFMAs per wave per K-step
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
   using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 2>;
@@ -857,6 +877,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
+    if (eff_tile_x(a) == XT_512x128W16) return launch_x<X512x128w16_3, true, false, false, true>(a, s);
     return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
@@ -869,6 +890,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
+      case XT_512x128W16: return launch_x<X512x128w16_3, true>(a, s);
     }
   } else {
     switch (tile) {

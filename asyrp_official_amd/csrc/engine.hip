@@ -689,8 +689,22 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
 }
 
 // softmax(Q K^T * scale) V over T tokens; qkv is [B][T][3C] (q|k|v, or per-head [q,k,v] blocks)
-int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scale, float* out /*[B][T][C]*/) {
+int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scale, float* out /*[B][T][C]*/,
+                   int force_unfused = 0) {
   const int Dh = C / heads;
+  // fused kernel (no T x T tensor in HBM) for the f16x3 engine; the fp32-MFMA engine and shapes it does not cover
+  // (T > 1024, heads wider than 512) keep the three-launch form below
+  if (c.e->math == MATH_F16X3 && !force_unfused && attn_fused_supported(T, Dh, 3 * C, C)) {
+    AttnArgs a;
+    memset(&a, 0, sizeof a);
+    a.qkv = qkv; a.ld = 3 * C; a.img_stride = (long long)T * 3 * C;
+    a.head_stride = (heads == 1) ? 0 : 3 * Dh;
+    a.q_off = 0; a.k_off = (heads == 1) ? C : Dh; a.v_off = (heads == 1) ? 2 * C : 2 * Dh;
+    a.B = c.B; a.heads = heads; a.T = T; a.Dh = Dh; a.scale = scale;
+    a.out = out; a.ldo = C; a.o_img_stride = (long long)T * C; a.o_head_stride = Dh;
+    const double fl = 4.0 * T * (double)T * C * c.B, by = 4.0 * 4.0 * T * (double)C * c.B;
+    return run_timed(c, 200000 + T, fl, by, [&]() { return launch_attention_fused(a, c.s); });
+  }
   float* Sbuf = nullptr;
   TRY(c.e->pool.get((size_t)c.B * heads * T * T, &Sbuf));
   const long long img = (long long)T * 3 * C;
@@ -1952,11 +1966,13 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   return 0;
 }
 
-int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream) {
+int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream) {
   if (!qkv || !out || B < 1 || heads < 1 || C % heads) return fail(ASYRP_EINVAL, "bad argument");
+  if (fused && !attn_fused_supported(T, C / heads, 3 * C, C)) return fail(ASYRP_EINVAL, "shape not covered by the fused attention kernel");
   HIPCHK(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
-  asyrp_engine tmp_e;   // only the pool is used
+  asyrp_engine tmp_e;   // only the pool (and the math switch) is used
+  tmp_e.math = fused ? MATH_F16X3 : MATH_F32;
   Ctx c{&tmp_e, s, B};
   float *q2 = nullptr, *o2 = nullptr;
   int rc = tmp_e.pool.get((size_t)B * T * 3 * C, &q2);

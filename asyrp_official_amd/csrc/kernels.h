@@ -44,6 +44,7 @@ struct GemmArgs {
   int sk; float* part;
   double* stats;                  // f16x3 only, nullable: per-(image, M-block, out channel) {sum, sumsq} of the output,
                                   //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
+  int xmap;                       // set by the f16x3 launcher: XCD-aware block -> tile map (see igemm_f16x3_kernel)
   int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
 };
 
@@ -53,7 +54,7 @@ enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_12
 
 // tile ids of the f16x3 family: 1 = 256x128, 4 waves, software-pipelined loop (big 1x1 layers; 3x3 A/B reference);
 // 6 = 256x128, 8 waves, per-tap loop (the big 3x3 layers and their fused shortcut); 12 = conv_out
-enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
+enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6, XT_512x128W16 = 7 /* experiment */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
@@ -106,6 +107,17 @@ struct GnFin2Args {
 hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s);
 
 hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s);
+
+// Fused attention (attention.hip): out[b][t][head*Dh + d] = sum_k softmax_k(scale * q_t.k_k) v_k[d], f16x3 matrix products.
+// qkv rows are tokens: element (b, t, .) at qkv + b*img_stride + head*head_stride + {q,k,v}_off + t*ld (+ channel).
+struct AttnArgs {
+  const float* qkv; int ld; long long img_stride, head_stride; int q_off, k_off, v_off;
+  int B, heads, T, Dh;
+  float scale;
+  float* out; int ldo; long long o_img_stride, o_head_stride;
+};
+bool attn_fused_supported(int T, int Dh, int ld, int ldo);
+hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s);
 
 // temb = dense1(swish(dense0(sinusoid(t)))) ; sin_first: DDPM [sin|cos] vs iDDPM [cos|sin]
 hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin_first, const float* w0,

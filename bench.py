@@ -103,8 +103,8 @@ def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=
     """The reference's own modules (kind="reference") when /root/reference (or $ASYRP_REFERENCE) is importable on this
     host, else the oracle restatement (kind="port"), timed on a bounded sample: B=1, 4 inversion steps + 4 Asyrp steps
     (dual decoder, as the reference executes them), extrapolated linearly to the 39 + 40 steps of one edit.
-    Thread count: the best of {16, 32, 64, all} visible cores on one warm forward (128 oversubscribed threads were
-    slower than 8 in round 1).  Also returns the CPU result of the first inversion step on `x_check` for the parity check."""
+    Thread count: the best of {16, 32, 64} threads on one warm forward each (one thread per visible core is far slower on
+    the 256-core GPU hosts: 102 s per forward vs 0.93 s at 16 threads, measured r02a).  Also returns the CPU result of the first inversion step on `x_check` for the parity check."""
     kind, step = _cpu_step_fn(model_cpu_sd, betas, family, learn_sigma)
     avail = len(os.sched_getaffinity(0))
     g = torch.Generator().manual_seed(1234)
@@ -112,7 +112,7 @@ def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=
     one = torch.ones(1)
     tried = {}
     step(x, one * 0.0, one * 25.0, eta=0)           # page in / warm caches
-    for n in sorted({min(n, avail) for n in (16, 32, 64, avail)}):
+    for n in sorted({min(n, avail) for n in (16, 32, 64)}):
         torch.set_num_threads(n)
         t0 = time.perf_counter()
         step(x, one * 0.0, one * 25.0, eta=0)

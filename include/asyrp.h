@@ -76,7 +76,7 @@ typedef struct asyrp_config {
 typedef struct asyrp_engine asyrp_engine;
 
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
-#define ASYRP_ABI_VERSION 4
+#define ASYRP_ABI_VERSION 5
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */
@@ -221,8 +221,10 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
                         void* stream);
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
- * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T]. */
-int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, float* out, void* stream);
+ * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T].
+ * fused != 0: the one-launch f16x3 kernel (csrc/attention.hip; T <= 1024, head width <= 512, multiple of 16), the engine's
+ * default; fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
+int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,9 @@ and records reference outputs as .npz fixtures next to this script:
   ddpm_celeba.npz  full CelebA-HQ DDPM (256x256, B=1): one single + one dual forward,
                    one Asyrp step, DeltaBlock = hash weights
   slerp_small.npz  both small UNets with an injected delta_h tensor (slerp branch, +/- use_mask)
+  config1_celeba_smiling.npz   BASELINE config 1 end to end: CelebA-HQ DDPM + the shipped `smiling` DeltaBlock, B=1,
+                   full 39 + 40 steps (t_addnoise = 0 and 167), per-step tensors for teacher-forced parity at full size
+  config3_afhq_dog_happy.npz   BASELINE config 3 generation phase: AFHQ iDDPM + the shipped `dog_happy` DeltaBlock
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; ~1 min on 8 cores)
 """
@@ -348,7 +351,7 @@ def run_config1(out, tame=1.0):
             if i >= 167:
                 continue
             xin = x
-            torch.manual_seed(0)          # randn_like is replaced below: feed the stored noise through the reference
+            # feed the stored noise through the reference's own torch.randn_like call (utils/diffusion_utils.py:97)
             z = noise[k]
             k += 1
             _orig = torch.randn_like
@@ -363,6 +366,52 @@ def run_config1(out, tame=1.0):
                 g["eta0.x_t"] = xin.clone()
         assert k == 7
         g["x_edit_noise"] = x.clone()
+    g["noise_probe"] = noise[:, 0, 0, 0, :8].clone()     # the test regenerates the noise from the seed and checks this slice
+    for k, v in sd.items():                               # the shipped DeltaBlock itself: /root/reference is not on the GPU box
+        if k.startswith("layer_0."):
+            g["param." + k] = v.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_config3(out):
+    """BASELINE config 3 (AFHQ-Dog iDDPM + the SHIPPED `dog_happy` DeltaBlock), generation phase from a seeded x_T through the
+    REFERENCE: B=1, 40 Asyrp steps, learn_sigma, t_edit=444 (utils/t_edit_dic.py:5).  Stored: x_edit and steps at t=999,
+    t=461 (last edited step), t=435 (first un-edited step), t=0 (t_next=-1)."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    torch.set_num_threads(os.cpu_count())
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    ck = torch.load(os.path.join(REF, "checkpoint", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"), map_location="cpu",
+                    weights_only=False)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    m = ref_iddpm(AFHQ, sd, 1)
+    x = hash_normal("config3.xT", (1, 3, 256, 256), seed=4321)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    seq, seq_next = _seq40()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", learn_sigma=True, index=0, t_edit=444,
+              hs_coeff=(1.0, 1.0))
+    one = torch.ones(1)
+    g = {}
+    with torch.no_grad():
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            xin = x
+            x, x0t, dh, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, **kw)
+            if i == 999:
+                g["gen999.xt_next"], g["gen999.x0_t"], g["gen999.delta_h"] = x.clone(), x0t.clone(), dh.clone()
+            if i == 461:
+                assert dh is not None
+                g["gen461.x_t"], g["gen461.xt_next"], g["gen461.delta_h"] = xin.clone(), x.clone(), dh.clone()
+            if i == 435:
+                assert dh is None
+                g["gen435.xt_next"] = x.clone()
+            if i == 0:
+                g["gen0.x_t"] = xin.clone()
+        g["x_edit"] = x.clone()
+    for k, v in sd.items():
+        if k.startswith("layer_0."):
+            g["param." + k] = v.clone()
     np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
@@ -396,3 +445,7 @@ if __name__ == "__main__":
         run_small(os.path.join(HERE, "ddpm_small.npz"))
     if a.only in (None, "celeba"):
         run_celeba(os.path.join(HERE, "ddpm_celeba.npz"))
+    if a.only in (None, "config1"):
+        run_config1(os.path.join(HERE, "config1_celeba_smiling.npz"))
+    if a.only in (None, "config3"):
+        run_config3(os.path.join(HERE, "config3_afhq_dog_happy.npz"))

@@ -1,0 +1,165 @@
+"""Parity AT THE CONFIGURATIONS THE BENCH RUNS: BASELINE.json configs[0]/[1] and [2] at full size
+against fixtures produced by running the REFERENCE itself end to end (tests/golden/make_golden.py run_config1 / run_config3):
+
+  * CelebA-HQ DDPM 256x256, hash base weights + the SHIPPED `smiling` DeltaBlock
+    (checkpoint/smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth["0"]), B=1, 39 inversion + 40 Asyrp steps, t_edit=500,
+    t_addnoise=0 and t_addnoise=167 with stored-seed noise;
+  * AFHQ-Dog iDDPM 256x256 + the shipped `dog_happy` DeltaBlock, 40 Asyrp steps from a seeded x_T, learn_sigma, t_edit=444.
+
+Teacher-forced steps (the GPU gets the reference's own x_t) are held to the north-star tolerance rtol=1e-3 / atol=1e-4.
+Free-running whole edits are compared too; the reference does not reproduce ITSELF at that tolerance there (measured with
+the reference on CPU, DESIGN.md §4: a 1-ulp change of x0 moves x_edit by 5.8e-2 max / 0.8 % of elements, 8 vs 5 threads by
+1.0e-2 / 0.11 %), so x_edit is bounded relative to the trajectory scale and x_T (benign direction) is held strictly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close, load_golden
+from oracle import sampler as osamp
+from oracle.weights import CELEBA, ddpm_param_shapes, hash_normal, hash_uniform, synthetic_state_dict
+from util_models import err_stats, hip_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(name):
+    p = os.path.join(GOLDEN, name)
+    if not os.path.exists(p):
+        pytest.skip(f"{name} not generated (tests/golden/make_golden.py --only ...)")
+    return load_golden(name)
+
+
+@pytest.fixture(scope="module")
+def config1():
+    g = _need("config1_celeba_smiling.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    torch.manual_seed(4321)
+    noise = torch.randn(7, 1, 3, 256, 256)
+    assert torch.equal(noise[:, 0, 0, 0, :8], g["noise_probe"]), "CPU generator stream differs from the fixture's"
+    return m, g, b, noise
+
+
+def _amp(b, t):
+    """x0_t = (x - eps*sqrt(1-a))/sqrt(a): an eps difference is multiplied by 1/sqrt(alpha_bar_t) (157 at t=999)."""
+    return max(1.0, float(osamp.alpha_bar(b)[t]) ** -0.5)
+
+
+def test_config1_teacher_forced_steps_full_size(config1):
+    m, g, b, noise = config1
+    x0 = hash_uniform("config1.x0", (1, 3, 256, 256), seed=1234).cuda()
+    eng = m._ready_engine(x0)
+    ek = dict(index=0, hs_coeff=(1.0, 1.0))
+    # first / last inversion step
+    xn, x0t, dh, _ = eng.ddim_step(x0, 0, 25)
+    assert dh is None
+    assert_close(xn, g["inv_first.xt_next"], what="inversion 0->25 xt_next")
+    assert_close(x0t, g["inv_first.x0_t"], atol=1e-4 * _amp(b, 0), what="inversion 0->25 x0_t")
+    xn, x0t, _, _ = eng.ddim_step(g["inv_last.x_t"].cuda(), 973, 999)
+    assert_close(xn, g["x_T"], what="inversion 973->999 xt_next (= x_T)")
+    assert_close(x0t, g["inv_last.x0_t"], atol=1e-4 * _amp(b, 973), what="inversion 973->999 x0_t")
+    # first generation step: dual decoder with the shipped smiling DeltaBlock
+    xn, x0t, dh, _ = eng.ddim_step(g["x_T"].cuda(), 999, 973, apply_edit=True, **ek)
+    assert_close(dh, g["gen999.delta_h"], what="t=999 delta_h (shipped DeltaBlock)")
+    assert_close(xn, g["gen999.xt_next"], what="t=999 xt_next")
+    assert_close(x0t, g["gen999.x0_t"], atol=1e-4 * _amp(b, 999), what="t=999 x0_t")
+    # last edited step (t = 512 >= t_edit), then the first step below t_edit (single decoder, et_mod == et)
+    xn, x0t, dh, _ = eng.ddim_step(g["gen512.x_t"].cuda(), 512, 486, apply_edit=True, **ek)
+    assert_close(dh, g["gen512.delta_h"], what="t=512 delta_h")
+    assert_close(xn, g["gen512.xt_next"], what="t=512 xt_next")
+    assert_close(x0t, g["gen512.x0_t"], atol=1e-4 * _amp(b, 512), what="t=512 x0_t")
+    xn, _, dh, _ = eng.ddim_step(g["gen512.xt_next"].cuda(), 486, 461, apply_edit=False, **ek)
+    assert dh is None
+    assert_close(xn, g["gen486.xt_next"], what="t=486 xt_next (below t_edit)")
+    # last step: t_next = -1 (alpha_bar_next = 1)
+    xn, x0t, _, _ = eng.ddim_step(g["gen0.x_t"].cuda(), 0, -1, apply_edit=False, **ek)
+    assert_close(xn, g["x_edit"], what="t=0 -> -1 xt_next (= x_edit)")
+    assert_close(x0t, g["x_edit"], what="t=0 -> -1 x0_t")
+    # eta = 1 steps of the stochastic tail (t < t_addnoise = 167), reference's own noise
+    xn, x0t, _, _ = eng.ddim_step(g["eta153.x_t"].cuda(), 153, 128, eta=1.0, noise=noise[0].cuda(), apply_edit=False, **ek)
+    assert_close(xn, g["eta153.xt_next"], what="eta=1 t=153 xt_next")
+    assert_close(x0t, g["eta153.x0_t"], atol=1e-4 * _amp(b, 153), what="eta=1 t=153 x0_t")
+    xn, _, _, _ = eng.ddim_step(g["eta0.x_t"].cuda(), 0, -1, eta=1.0, noise=noise[6].cuda(), apply_edit=False, **ek)
+    assert_close(xn, g["x_edit_noise"], what="eta=1 t=0 -> -1 xt_next (= x_edit with noise)")
+
+
+def test_config1_whole_edit_free_running(config1):
+    """BASELINE config 1 executed end to end on the engine (one asyrp_run_edit call per variant) vs the reference's x_T / x_edit."""
+    from asyrp_official_amd import run_edit
+    m, g, b, noise = config1
+    x0 = hash_uniform("config1.x0", (1, 3, 256, 256), seed=1234).cuda()
+    x_edit, x_T = run_edit(m, x0, b, n_inv=40, n_gen=40, t_edit=500, t_addnoise=0, want_latent=True)
+    st_T, st_e = err_stats(x_T, g["x_T"]), err_stats(x_edit, g["x_edit"])
+    print("config1 free-running x_T", st_T)
+    print("config1 free-running x_edit", st_e)
+    assert_close(x_T, g["x_T"], what="x_T after 39 inversion steps")          # strict
+    assert st_e["max_abs"] <= 3e-4 * st_e["ref_absmax"] and st_e["frac_outside"] <= 0.02
+    x_edit_n = run_edit(m, x0, b, n_inv=40, n_gen=40, t_edit=500, t_addnoise=167, noise=noise.cuda())
+    st_n = err_stats(x_edit_n, g["x_edit_noise"])
+    print("config1 free-running x_edit (t_addnoise=167)", st_n)
+    assert st_n["max_abs"] <= 3e-4 * st_n["ref_absmax"] and st_n["frac_outside"] <= 0.02
+
+
+def test_config1_tame_weights_whole_edit_strict():
+    """The same 39+40 edit with conv_out scaled by 0.02 (the reference then reproduces itself to ~1e-5 under a 1-ulp input
+    change): here the FREE-RUNNING x_T and x_edit are held to the north-star tolerance itself."""
+    from asyrp_official_amd import run_edit
+    g = _need("config1_celeba_tame.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    big = load_golden("config1_celeba_smiling.npz")
+    for k in list(big):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = big[k]
+    tame = float(g["tame"])
+    sd["conv_out.weight"] = sd["conv_out.weight"] * tame
+    sd["conv_out.bias"] = sd["conv_out.bias"] * tame
+    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    b = osamp.beta_schedule()
+    x0 = hash_uniform("config1.x0", (1, 3, 256, 256), seed=1234).cuda()
+    x_edit, x_T = run_edit(m, x0, b, n_inv=40, n_gen=40, t_edit=500, t_addnoise=0, want_latent=True)
+    print("tame x_T", err_stats(x_T, g["x_T"]), "x_edit", err_stats(x_edit, g["x_edit"]))
+    assert_close(x_T, g["x_T"], what="tame x_T")
+    assert_close(x_edit, g["x_edit"], what="tame x_edit (free-running 39+40 steps)")
+
+
+def test_config3_afhq_teacher_forced_and_free_running():
+    from asyrp_official_amd import i_DDPM, run_edit
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    g = _need("config3_afhq_dog_happy.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    m = i_DDPM("AFHQ", max_batch=2)
+    m.setattr_layers(1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda().eval()
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    x_T = hash_normal("config3.xT", (1, 3, 256, 256), seed=4321).cuda()
+    eng = m._ready_engine(x_T)
+    ek = dict(index=0, hs_coeff=(1.0, 1.0), learn_sigma=True)
+    xn, x0t, dh, _ = eng.ddim_step(x_T, 999, 973, apply_edit=True, **ek)
+    assert_close(dh, g["gen999.delta_h"], what="t=999 delta_h (shipped dog_happy DeltaBlock)")
+    assert_close(xn, g["gen999.xt_next"], what="t=999 xt_next")
+    assert_close(x0t, g["gen999.x0_t"], atol=1e-4 * _amp(b, 999), what="t=999 x0_t")
+    xn, _, dh, _ = eng.ddim_step(g["gen461.x_t"].cuda(), 461, 435, apply_edit=True, **ek)     # 461 >= t_edit = 444
+    assert_close(dh, g["gen461.delta_h"], what="t=461 delta_h")
+    assert_close(xn, g["gen461.xt_next"], what="t=461 xt_next")
+    xn, _, dh, _ = eng.ddim_step(g["gen461.xt_next"].cuda(), 435, 409, apply_edit=False, **ek)
+    assert dh is None
+    assert_close(xn, g["gen435.xt_next"], what="t=435 xt_next (below t_edit)")
+    xn, _, _, _ = eng.ddim_step(g["gen0.x_t"].cuda(), 0, -1, apply_edit=False, **ek)
+    assert_close(xn, g["x_edit"], what="t=0 -> -1 xt_next (= x_edit)")
+    x_edit = run_edit(m, x_T, b, n_gen=40, t_edit=444, learn_sigma=True, invert=False)
+    st = err_stats(x_edit, g["x_edit"])
+    print("config3 free-running x_edit", st)
+    assert st["max_abs"] <= 3e-4 * max(1.0, st["ref_absmax"]) and st["frac_outside"] <= 0.02

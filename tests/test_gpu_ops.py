@@ -88,14 +88,14 @@ def test_f16x3_narrow_tile_for_conv_out():
         assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out tile {tile} Cout {Cout}", **TIGHT)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
     """Force each compiled tile shape of the f16x3 family (256x128 4-wave, 128x128, 64x128, 64x64, 256x64, 256x128
     8-wave) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32 concatenated channels, 160 output
     channels (partial N tile)."""
-    if tile == 6 and k == 1:
-        pytest.skip("the 8-wave tile is compiled for 3x3 convolutions only")
+    if tile in (6, 7) and k == 1:
+        pytest.skip("the 8- and 16-wave tiles are compiled for 3x3 convolutions only")
     B, H, W = 2, 40, 24
     x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
     x1 = hash_normal(f"tile.x1.{k}", (B, 32, H, W)) * 3.0
@@ -272,14 +272,25 @@ def test_gn_large_mean_offset_is_stable():
                  rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,C,T,heads", [(2, 64, 64, 1), (1, 512, 256, 1), (2, 128, 64, 2), (1, 512, 256, 8)])
-def test_attention(B, C, T, heads):
+ATT_CASES = [
+    # (B, C, T, heads, fused)
+    (2, 64, 64, 1, 0), (1, 512, 256, 1, 0), (2, 128, 64, 2, 0), (1, 512, 256, 8, 0),          # unfused fp32-MFMA path
+    (2, 64, 64, 1, 1), (1, 512, 256, 1, 1), (2, 512, 64, 1, 1),                               # DDPM AttnBlock: one 512-wide head
+    (2, 128, 64, 2, 1), (1, 512, 256, 8, 1), (1, 512, 64, 8, 1),                              # AFHQ iDDPM: 64-channel heads
+    (1, 512, 1024, 8, 1), (1, 1024, 256, 16, 1), (1, 1024, 64, 16, 1),                        # ImageNet ADM sites (T = 1024 at 32x32)
+    (2, 64, 256, 4, 1), (1, 32, 16, 2, 1),                                                    # toy UNets: 16-channel heads
+    (1, 128, 96, 2, 1), (1, 64, 520, 1, 1),                                                   # ragged T: key / query masking
+]
+
+
+@pytest.mark.parametrize("B,C,T,heads,fused", ATT_CASES)
+def test_attention(B, C, T, heads, fused):
     from asyrp_official_amd import _lib
     lib = _lib.load()
     qkv = hash_normal(f"att.{B}.{C}.{T}.{heads}", (B, 3 * C, T))
     out = torch.empty((B, C, T), device="cuda")
     qd = qkv.cuda()
-    _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, _p(out), None))
+    _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, fused, _p(out), None))
     torch.cuda.synchronize()
     if heads == 1:      # models/ddpm/diffusion.py:205-221
         q, k, v = qkv.split(C, dim=1)

@@ -225,3 +225,34 @@ def test_injected_delta_h_slerp_branch_both_families():
             assert_close(xn, g[f"{name}.step.xt_next"], what=f"{name} step xt_next", **tol)
             # x0_t = (xt - et*sqrt(1-at))/sqrt(at) amplifies the forward's summation-order noise by 1/sqrt(at) ~ 14 at t=701
             assert_close(x0t, g[f"{name}.step.x0_t"], what=f"{name} step x0_t", rtol=1e-5, atol=5e-5)
+
+
+def test_oracle_on_config1_steps_with_shipped_delta_block():
+    """The oracle against the reference's own full-size config-1 trajectory (CelebA-HQ 256x256 + the shipped `smiling`
+    DeltaBlock): one edited step (t=512, dual decoder) and one eta=1 step, from the reference's x_t."""
+    import os
+    import pytest
+    from conftest import GOLDEN, load_golden
+    from oracle.weights import CELEBA
+    if not os.path.exists(os.path.join(GOLDEN, "config1_celeba_smiling.npz")):
+        pytest.skip("config1 fixture not generated")
+    g = load_golden("config1_celeba_smiling.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    model = sampler.make_model(sd, CELEBA)
+    b = sampler.beta_schedule()
+    one = torch.ones(1)
+    loose = dict(rtol=1e-4, atol=2e-5)      # thread-count dependent summation order at 256x256 (1e-6 per forward)
+    xn, x0t, dh, _ = sampler.denoising_step(g["gen512.x_t"], one * 512, one * 486, model=model, b=b, eta=0.0, index=0,
+                                            t_edit=500, hs_coeff=(1.0, 1.0))
+    assert_close(dh, g["gen512.delta_h"], what="delta_h", **loose)
+    assert_close(xn, g["gen512.xt_next"], what="xt_next", **loose)
+    assert_close(x0t, g["gen512.x0_t"], what="x0_t", rtol=1e-4, atol=2e-4)
+    torch.manual_seed(4321)
+    noise = torch.randn(7, 1, 3, 256, 256)
+    assert torch.equal(noise[:, 0, 0, 0, :8], g["noise_probe"])
+    xn, x0t, _, _ = sampler.denoising_step(g["eta153.x_t"], one * 153, one * 128, model=model, b=b, eta=1.0, index=0,
+                                           t_edit=500, hs_coeff=(1.0, 1.0), noise=noise[0])
+    assert_close(xn, g["eta153.xt_next"], what="eta xt_next", **loose)
