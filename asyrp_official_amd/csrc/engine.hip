@@ -74,10 +74,20 @@ struct Pool {
     *out = p;
     return 0;
   }
+  // training forward: buffers the inference schedule would recycle are HELD instead (the backward pass reads them);
+  // release_held() returns them after the backward (or when the tape is discarded)
+  bool defer = false;
+  std::vector<float*> held_;
   void put(float* p) {
     if (!p) return;
     auto it = size_.find(p);
-    if (it != size_.end() && live_.erase(p)) free_.emplace(it->second, p);
+    if (it == size_.end() || !live_.erase(p)) return;
+    if (defer) held_.push_back(p);
+    else free_.emplace(it->second, p);
+  }
+  void release_held() {
+    for (float* p : held_) free_.emplace(size_[p], p);
+    held_.clear();
   }
   // end of an ABI call: whatever an error path left outstanding goes back to the free lists
   void reclaim() {
@@ -89,6 +99,7 @@ struct Pool {
     size_.clear();
     free_.clear();
     live_.clear();
+    held_.clear();
     total_bytes = 0;
   }
 };
@@ -108,6 +119,27 @@ struct ProfRec {
   double flops, bytes;
 };
 
+// ---- what the training forward keeps for the backward pass through decoder #2 and the DeltaBlock (DDPM family) ----
+struct TapeRes { std::string p; Act x0, x1; bool has_x1 = false; Act h1; float *sc1 = nullptr, *sh1 = nullptr, *mr1 = nullptr,
+                 *sc2 = nullptr, *sh2 = nullptr, *mr2 = nullptr; int Cout = 0; bool shortcut = false; };
+struct TapeAttn { std::string p; Act x, qkv; float *sc = nullptr, *sh = nullptr, *mr = nullptr, *P = nullptr; };
+struct TapeUp { std::string p; int C = 0, H = 0, W = 0; };
+struct TapeEntry { int type; int idx; };   // 0 ResnetBlock, 1 AttnBlock, 2 Upsample (forward order)
+struct Tape {
+  bool valid = false;
+  int B = 0;
+  std::vector<TapeEntry> order;
+  std::vector<TapeRes> res;
+  std::vector<TapeAttn> attn;
+  std::vector<TapeUp> up;
+  Act out_h; float *out_sc = nullptr, *out_sh = nullptr, *out_mr = nullptr;      // norm_out input and its GroupNorm terms
+  Act d_h, d_d1; float *d_sc = nullptr, *d_sh = nullptr, *d_mr = nullptr;        // DeltaBlock: bottleneck h, conv1 output
+  bool d_temb = true;
+  float c1 = 1.f;
+  float* temb_act = nullptr;            // swish(temb) [B][temb_ch]
+  void clear() { valid = false; order.clear(); res.clear(); attn.clear(); up.clear(); }
+};
+
 }  // namespace
 
 struct asyrp_engine {
@@ -122,6 +154,8 @@ struct asyrp_engine {
   hipStream_t bound_stream = nullptr;   // stream of the previous compute call (workspace reuse is ordered on it)
   bool has_bound = false;
   hipEvent_t bind_ev = nullptr;
+  Tape tape;                            // asyrp_train_forward -> asyrp_train_backward
+  bool bwd_weights = false;             // transposed decoder weight images built (first training call)
 
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
   struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; };
@@ -464,6 +498,7 @@ struct Ctx {
   float* tproj = nullptr;   // [B][tproj_total]
   const float* dh_in = nullptr;   // injected delta-h tensor (NHWC) -> slerp mix instead of the DeltaBlocks
   int use_mask = 0;
+  Tape* tape = nullptr;           // non-null while the training forward runs the DeltaBlock and decoder #2
 };
 
 float* P(Ctx& c, const std::string& name) {
@@ -529,7 +564,7 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
          const Act* resid, Act* out, bool want_stats = false, int rups = 0, const Act* sc0 = nullptr,
-         const Act* sc1 = nullptr, bool* fused = nullptr) {
+         const Act* sc1 = nullptr, bool* fused = nullptr, int ldb_full = 0) {
   const int Hin = x0.H, Win = x0.W;
   int Ho = Hin, Wo = Win;
   if (ups) { Ho *= 2; Wo *= 2; }
@@ -547,7 +582,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.pscale = pscale; g.pshift = pshift; g.silu = silu;
   g.w = P(c, wname);
   if (!g.w) return fail(ASYRP_EKEY, "missing packed weight " + wname);
-  g.ldb = Cout;
+  g.ldb = ldb_full ? ldb_full : Cout;   // (a launch may use the leading Cout columns of a wider packed weight)
   g.bias = bname.empty() ? nullptr : P(c, bname);
   g.chan_add = chan_add; g.ld_chan_add = c.e->tproj_total;
   if (resid) { g.resid = resid->p; g.ldr = resid->C; g.r_zo = resid->per_image(); g.rups = rups; }
@@ -620,7 +655,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
 // Per-channel partial statistics come from the producing conv's epilogue when it wrote them (Act::st); a tensor without
 // them (h-space mix output, fp32-MFMA mode) gets one standalone reduction pass.
 int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float eps, float** scale, float** shift,
-       const float* film_scale = nullptr, const float* film_shift = nullptr, int ld_film = 0) {
+       const float* film_scale = nullptr, const float* film_shift = nullptr, int ld_film = 0, float** mr = nullptr) {
   const int C = x0.C + (x1 ? x1->C : 0);
   const int HW = x0.H * x0.W;
   TRY(c.e->pool.get((size_t)c.B * C, scale));
@@ -650,6 +685,10 @@ int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float ep
   a.eps = eps;
   a.film_scale = film_scale; a.film_shift = film_shift; a.ld_film = ld_film;
   a.scale = *scale; a.shift = *shift;
+  if (mr) {
+    TRY(c.e->pool.get((size_t)c.B * 64, mr));
+    a.mr = *mr;
+  }
   HIPCHK(launch_gn_finalize2(a, c.s));
   for (int k = 0; k < 2; ++k)
     if (tmp[k]) c.e->pool.put(tmp[k]);
@@ -661,13 +700,23 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
   asyrp_engine* e = c.e;
   const int Cin = x0.C + (x1 ? x1->C : 0);
   const int Cout = (int)e->specs[e->spec_idx.at(p + ".conv1.bias")].shape[0];
-  float *sc1, *sh1, *sc2, *sh2;
-  TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1));
+  float *sc1, *sh1, *sc2, *sh2, *mr1 = nullptr, *mr2 = nullptr;
+  TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1, nullptr, nullptr, 0, c.tape ? &mr1 : nullptr));
   Act h1;
   TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
            c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
   e->pool.put(sc1); e->pool.put(sh1);
-  TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2));
+  TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2, nullptr, nullptr, 0, c.tape ? &mr2 : nullptr));
+  if (c.tape) {   // (the pool defers every put while a tape is recorded: the pointers below stay valid until the backward)
+    TapeRes t;
+    t.p = p; t.x0 = x0; t.has_x1 = (x1 != nullptr);
+    if (x1) t.x1 = *x1;
+    t.h1 = h1; t.sc1 = sc1; t.sh1 = sh1; t.mr1 = mr1; t.sc2 = sc2; t.sh2 = sh2; t.mr2 = mr2;
+    t.Cout = Cout; t.shortcut = (Cin != Cout);
+    c.tape->order.push_back({0, (int)c.tape->res.size()});
+    c.tape->res.push_back(t);
+    e->pool.put(mr1); e->pool.put(mr2);
+  }
   if (Cin != Cout) {
     // x + h with x = nin_shortcut(x): the 1x1 rides in conv2's K-loop when the launch runs on the fusing tile
     bool fused = false;
@@ -690,7 +739,7 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
 
 // softmax(Q K^T * scale) V over T tokens; qkv is [B][T][3C] (q|k|v, or per-head [q,k,v] blocks)
 int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scale, float* out /*[B][T][C]*/,
-                   int force_unfused = 0) {
+                   int force_unfused = 0, float** keep_P = nullptr) {
   const int Dh = C / heads;
   // fused kernel (no T x T tensor in HBM) for the f16x3 engine; the fp32-MFMA engine and shapes it does not cover
   // (T > 1024, heads wider than 512) keep the three-launch form below
@@ -730,20 +779,29 @@ int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scal
   g.out = out; g.ldo = C; g.o_zo = (long long)T * C; g.o_zi = Dh;
   g.ZI = heads; g.Z = c.B * heads;
   TRY(run_gemm(c, g));
+  if (keep_P) *keep_P = Sbuf;      // softmax probabilities [B][heads][T][T], read by the attention backward
   c.e->pool.put(Sbuf);
   return 0;
 }
 
 // AttnBlock (models/ddpm/diffusion.py:200-225): GN -> fused q|k|v 1x1 -> attention -> proj_out -> + x
 int attnblock(Ctx& c, const std::string& p, const Act& x, Act* out) {
-  float *sc, *sh;
-  TRY(gn(c, x, nullptr, p + ".norm", 1e-6f, &sc, &sh));
+  float *sc, *sh, *mr = nullptr, *Pk = nullptr;
+  TRY(gn(c, x, nullptr, p + ".norm", 1e-6f, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
   Act qkv;
   TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
   c.e->pool.put(sc); c.e->pool.put(sh);
   Act o;
   TRY(new_act(c, x.C, x.H, x.W, &o));
-  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, 1, 1.0f / std::sqrt((float)x.C), o.p));
+  // training: the three-launch form keeps the softmax probabilities for the backward pass
+  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, 1, 1.0f / std::sqrt((float)x.C), o.p, c.tape ? 1 : 0, c.tape ? &Pk : nullptr));
+  if (c.tape) {
+    TapeAttn t;
+    t.p = p; t.x = x; t.qkv = qkv; t.sc = sc; t.sh = sh; t.mr = mr; t.P = Pk;
+    c.tape->order.push_back({1, (int)c.tape->attn.size()});
+    c.tape->attn.push_back(t);
+    c.e->pool.put(mr);
+  }
   drop(c, qkv);
   TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr,
            &x, out, true));
@@ -756,8 +814,12 @@ int deltablock(Ctx& c, const std::string& p, const Act& h, bool use_temb, Act* o
   Act d1;
   TRY(conv(c, h, nullptr, p + ".conv1.weight", p + ".conv1.bias", h.C, 1, 1, 0, nullptr, nullptr, 0,
            use_temb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1, true));
-  float *sc, *sh;
-  TRY(gn(c, d1, nullptr, p + ".norm2", 1e-6f, &sc, &sh));
+  float *sc, *sh, *mr = nullptr;
+  TRY(gn(c, d1, nullptr, p + ".norm2", 1e-6f, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
+  if (c.tape) {
+    c.tape->d_h = h; c.tape->d_d1 = d1; c.tape->d_sc = sc; c.tape->d_sh = sh; c.tape->d_mr = mr; c.tape->d_temb = use_temb;
+    c.e->pool.put(mr);
+  }
   TRY(conv(c, d1, nullptr, p + ".conv2.weight", p + ".conv2.bias", h.C, 1, 1, 0, sc, sh, 1, nullptr, nullptr, out));
   c.e->pool.put(sc); c.e->pool.put(sh);
   drop(c, d1);
@@ -792,14 +854,24 @@ int decoder(Ctx& c, const Act& hin, const std::vector<Act>& skips, Act* eps) {
       Act o;
       TRY(conv(c, h, nullptr, S("up.%d.upsample.conv.weight", i), S("up.%d.upsample.conv.bias", i), h.C, 3, 1, 1,
                nullptr, nullptr, 0, nullptr, nullptr, &o, true));
+      if (c.tape) {
+        TapeUp t;
+        t.p = S("up.%d.upsample.conv", i); t.C = h.C; t.H = h.H; t.W = h.W;
+        c.tape->order.push_back({2, (int)c.tape->up.size()});
+        c.tape->up.push_back(t);
+      }
       replace(o);
       res *= 2;
     }
   }
-  float *sc, *sh;
-  TRY(gn(c, h, nullptr, "norm_out", 1e-6f, &sc, &sh));
+  float *sc, *sh, *mr = nullptr;
+  TRY(gn(c, h, nullptr, "norm_out", 1e-6f, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
   TRY(conv(c, h, nullptr, "conv_out.weight", "conv_out.bias", cf.out_channels, 3, 1, 0, sc, sh, 1, nullptr, nullptr,
            eps));
+  if (c.tape) {
+    c.tape->out_h = h; c.tape->out_sc = sc; c.tape->out_sh = sh; c.tape->out_mr = mr;
+    c.e->pool.put(mr);
+  }
   c.e->pool.put(sc); c.e->pool.put(sh);
   if (own) drop(c, h);
   return 0;
@@ -1039,6 +1111,9 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
                          c.B, c.s));
   HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
                             e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
+  c.tape = nullptr;
+  if (tape) tape->temb_act = temb_act;
   e->pool.put(temb);
   e->pool.put(temb_act);
 
@@ -1092,6 +1167,8 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     std::vector<Act> deltas(index + 1);
     const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
+    if (tape && index != 0) return fail(ASYRP_EINVAL, "the training step supports one DeltaBlock (index 0)");
+    c.tape = tape;
     for (int i = 0; i <= index; ++i) {
       TRY(deltablock(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
       dptr[i] = deltas[i].p;
@@ -1101,7 +1178,9 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
     for (int i = 0; i < index; ++i) drop(c, deltas[i]);
     *last_delta = deltas[index];
+    if (tape) tape->c1 = coeff[1];
     TRY(decoder(c, h2, skips, et_mod));
+    c.tape = nullptr;
     drop(c, h2);
   }
   TRY(decoder(c, h, skips, et));
@@ -1161,6 +1240,175 @@ int ddim_apply(Ctx& c, const float* x, const Act& et, const Act& et_mod, const f
   a.xt_next = xn; a.x0_t = x0t;
   a.npix = (long long)c.B * et.H * et.W;
   HIPCHK(launch_ddim(a, c.s));
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// Training step of the DeltaBlock (diffusion_latent.py:301-354, DDPM family):
+//   forward  = one Asyrp step (dual decoder) that keeps decoder #2's activations ("tape");
+//   backward = d(loss)/d(et_modified) -> data gradients through decoder #2 (transposed convolutions on the same
+//              implicit-GEMM kernels, GroupNorm/SiLU/attention/upsample backward glue from backward.hip) -> d(h2)
+//              -> DeltaBlock parameter gradients.  The loss itself (CLIP direction + L1) stays in the caller's PyTorch.
+// =====================================================================================================
+namespace {
+
+// conv weight [Cout][Cin][k][k] -> the weight of the data-gradient convolution [Cin][Cout][k][k], taps rotated by 180 degrees
+std::vector<float> transpose_conv_weight(const std::vector<float>& w, int cout, int cin, int k) {
+  std::vector<float> o((size_t)cout * cin * k * k);
+  const int kk = k * k;
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < kk; ++t) o[((size_t)ci * cout + co) * kk + (kk - 1 - t)] = w[((size_t)co * cin + ci) * kk + t];
+  return o;
+}
+
+int add_bwd_weight(asyrp_engine* e, const std::string& name, const std::vector<float>& wT, int cout_t, int cin_t, int k) {
+  TRY(upload(e, name, pack_conv(wT, cout_t, cin_t, k)));
+  if (e->math == MATH_F16X3) TRY(pack_x3(e, name, wT, cout_t, cin_t, k));
+  return 0;
+}
+
+// transposed images of every decoder convolution (+ the DeltaBlock's second conv); built on the first training call
+int ensure_bwd_weights(asyrp_engine* e) {
+  if (e->bwd_weights) return 0;
+  if (e->cfg.family != ASYRP_FAMILY_DDPM) return fail(ASYRP_EINVAL, "the training step is implemented for the DDPM UNet family");
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& s : e->specs) {
+    if (s.shape.size() != 4) continue;
+    const bool dec = s.key.rfind("up.", 0) == 0 || s.key.rfind("conv_out.", 0) == 0 || s.key == "layer_0.conv2.weight";
+    if (!dec) continue;
+    const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (int)s.shape[2];
+    const std::string p = s.key.substr(0, s.key.size() - strlen(".weight"));
+    if (ends_with(p, ".k") || ends_with(p, ".v")) continue;
+    if (ends_with(p, ".q")) {   // fused q|k|v [3C][C] -> [C][3C]
+      const std::string ap = p.substr(0, p.size() - 2);
+      std::vector<float> w3((size_t)3 * cout * cin);
+      const char* names[3] = {".q", ".k", ".v"};
+      for (int t = 0; t < 3; ++t) {
+        const auto& wt = hostp(e, ap + names[t] + ".weight");
+        std::copy(wt.begin(), wt.end(), w3.begin() + (size_t)t * cout * cin);
+      }
+      TRY(add_bwd_weight(e, ap + ".qkv.weight#T", transpose_conv_weight(w3, 3 * cout, cin, 1), cin, 3 * cout, 1));
+      continue;
+    }
+    TRY(add_bwd_weight(e, s.key + "#T", transpose_conv_weight(hostp(e, s.key), cout, cin, k), cin, cout, k));
+  }
+  e->bwd_weights = true;
+  return 0;
+}
+
+// GroupNorm (+SiLU) backward of y = act(GN(x)) given dA = dL/dy: returns dx for the leading Cd channels of x (+ `add`)
+int act_gn_backward(Ctx& c, const Act& dA, const Act& x0, const Act* x1, const float* sc, const float* sh, const float* mr,
+                    const std::string& norm, int silu, int Cd, const Act* add, Act* dx) {
+  const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
+  if (dA.C != C) return fail(ASYRP_EINVAL, "gradient / activation channel mismatch at " + norm);
+  Act dy;
+  TRY(new_act(c, C, x0.H, x0.W, &dy));
+  const int nblk = act_bwd_nblk(HW);
+  float *part, *coef;
+  TRY(c.e->pool.get((size_t)c.B * nblk * C * 4, &part));
+  TRY(c.e->pool.get((size_t)c.B * C * 3, &coef));
+  ActBwdArgs a;
+  memset(&a, 0, sizeof a);
+  a.dA = dA.p; a.ldd = dA.C;
+  a.x0 = x0.p; a.c0 = x0.C; a.ldx0 = x0.C; a.x0_z = x0.per_image();
+  if (x1) { a.x1 = x1->p; a.c1 = x1->C; a.ldx1 = x1->C; a.x1_z = x1->per_image(); }
+  a.scale = sc; a.shift = sh; a.silu = silu; a.dy = dy.p; a.partial = reinterpret_cast<double*>(part);
+  a.HW = HW; a.N = c.B; a.C = C;
+  HIPCHK(launch_act_bwd_partial(a, c.s));
+  GnBwdFinArgs f;
+  memset(&f, 0, sizeof f);
+  f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, norm + ".weight"); f.mr = mr; f.N = c.B; f.HW = HW; f.C = C; f.coef = coef;
+  if (!f.gamma) return fail(ASYRP_EKEY, "missing norm params " + norm);
+  HIPCHK(launch_gn_bwd_finalize(f, c.s));
+  TRY(new_act(c, Cd, x0.H, x0.W, dx));
+  HIPCHK(launch_gn_bwd_apply(dy.p, C, x0.p, x0.C, x0.per_image(), coef, add ? add->p : nullptr, dx->p, Cd, HW, c.B, c.s));
+  c.e->pool.put(part); c.e->pool.put(coef);
+  drop(c, dy);
+  return 0;
+}
+
+// transposed convolution of a gradient tensor: dX = conv(dY, W^T rot180) -- same geometry as the forward (stride 1)
+int conv_bwd_data(Ctx& c, const Act& dY, const std::string& wname_fwd, int Cin_fwd, int ks, const Act* add, Act* dX,
+                  int ldb_full = 0) {
+  return conv(c, dY, nullptr, wname_fwd + "#T", "", Cin_fwd, ks, 1, 0, nullptr, nullptr, 0, nullptr, add, dX, false, 0, nullptr,
+              nullptr, nullptr, ldb_full);
+}
+
+int resblock_backward(Ctx& c, const TapeRes& t, const Act& d_out, Act* d_in) {
+  const int Cin = t.x0.C + (t.has_x1 ? t.x1.C : 0), Ch = t.x0.C;
+  Act dA2, d_h1, dA1;
+  TRY(conv_bwd_data(c, d_out, t.p + ".conv2.weight", t.Cout, 3, nullptr, &dA2));
+  TRY(act_gn_backward(c, dA2, t.h1, nullptr, t.sc2, t.sh2, t.mr2, t.p + ".norm2", 1, t.Cout, nullptr, &d_h1));
+  drop(c, dA2);
+  TRY(conv_bwd_data(c, d_h1, t.p + ".conv1.weight", Cin, 3, nullptr, &dA1));
+  drop(c, d_h1);
+  Act d_short;
+  const Act* add = &d_out;     // identity shortcut: x + h
+  if (t.shortcut) {            // 1x1 nin_shortcut: only the gradient of the leading Ch input channels (the h part) is needed
+    TRY(conv_bwd_data(c, d_out, t.p + ".nin_shortcut.weight", Ch, 1, nullptr, &d_short, Cin));
+    add = &d_short;
+  } else if (Ch != t.Cout) {
+    return fail(ASYRP_EINVAL, "identity shortcut with a channel change");
+  }
+  TRY(act_gn_backward(c, dA1, t.x0, t.has_x1 ? &t.x1 : nullptr, t.sc1, t.sh1, t.mr1, t.p + ".norm1", 1, Ch, add, d_in));
+  drop(c, dA1);
+  if (t.shortcut) drop(c, d_short);
+  return 0;
+}
+
+// one batched fp32-MFMA GEMM per image: out[z][m][n] = sum_k A[z][m][k] * B[z][k][n]  (bT: B[z][k][n] = Bt[z][n][k])
+int bgemm(Ctx& c, const float* A, int lda, long long a_z, const float* Bm, int ldb, long long b_z, int bT, int M, int N, int K,
+          float* out, int ldo, long long o_z, int Z) {
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = A; g.c0 = K; g.lda0 = lda; g.a0_zo = a_z;
+  g.Hin = M; g.Win = 1; g.Hout = M; g.Wout = 1; g.Cin = K; g.Cout = N; g.ks = 1; g.stride = 1;
+  g.w = Bm; g.ldb = ldb; g.bT = bT; g.w_zo = b_z;
+  g.alpha = 1.0f; g.out = out; g.ldo = ldo; g.o_zo = o_z; g.ZI = 1; g.Z = Z; g.math = MATH_F32;
+  return run_gemm(c, g);
+}
+
+int attnblock_backward(Ctx& c, const TapeAttn& t, const Act& d_out, Act* d_in) {
+  const int C = t.x.C, T = t.x.H * t.x.W, B = c.B;
+  const float scale = 1.0f / std::sqrt((float)C);
+  Act d_o;
+  TRY(conv_bwd_data(c, d_out, t.p + ".proj_out.weight", C, 1, nullptr, &d_o));
+  const float* q = t.qkv.p; const float* k = t.qkv.p + C; const float* v = t.qkv.p + 2 * C;
+  const long long qz = (long long)T * 3 * C, tz = (long long)T * T;
+  float *dP, *tr;
+  TRY(c.e->pool.get((size_t)B * T * T, &dP));
+  TRY(c.e->pool.get((size_t)B * T * T, &tr));
+  Act dqkv;
+  TRY(new_act(c, 3 * C, t.x.H, t.x.W, &dqkv));
+  // dP = d_o V^T ; dS = P * (dP - rowsum(dP * P)) * scale
+  TRY(bgemm(c, d_o.p, C, (long long)T * C, v, 3 * C, qz, 1, T, T, C, dP, T, tz, B));
+  HIPCHK(launch_softmax_bwd(t.P, dP, (long long)B * T, T, scale, c.s));
+  // dQ = dS K ; dK = dS^T Q ; dV = P^T d_o
+  TRY(bgemm(c, dP, T, tz, k, 3 * C, qz, 0, T, C, T, dqkv.p, 3 * C, qz, B));
+  HIPCHK(launch_transpose(dP, T, tz, tr, T, T, tz, B, c.s));
+  TRY(bgemm(c, tr, T, tz, q, 3 * C, qz, 0, T, C, T, dqkv.p + C, 3 * C, qz, B));
+  HIPCHK(launch_transpose(t.P, T, tz, tr, T, T, tz, B, c.s));
+  TRY(bgemm(c, tr, T, tz, d_o.p, C, (long long)T * C, 0, T, C, T, dqkv.p + 2 * C, 3 * C, qz, B));
+  c.e->pool.put(dP); c.e->pool.put(tr);
+  drop(c, d_o);
+  Act d_n;
+  TRY(conv_bwd_data(c, dqkv, t.p + ".qkv.weight", C, 1, nullptr, &d_n));
+  drop(c, dqkv);
+  TRY(act_gn_backward(c, d_n, t.x, nullptr, t.sc, t.sh, t.mr, t.p + ".norm", 0, C, &d_out, d_in));
+  drop(c, d_n);
+  return 0;
+}
+
+// gradient of a [Cout][Cin] matrix W used as y[m][co] = sum_ci x[m][ci] W[co][ci]:  dW = dY^T X  (M rows)
+int weight_grad(Ctx& c, const float* dY, int Cout, const float* X, int Cin, long long M, float* dW /*device [Cout][Cin]*/) {
+  float* dYt;
+  TRY(c.e->pool.get((size_t)Cout * M, &dYt));
+  HIPCHK(launch_transpose(dY, Cout, 0, dYt, (int)M, Cout, 0, 1, c.s));
+  TRY(bgemm(c, dYt, (int)M, 0, X, Cin, 0, 0, Cout, Cin, (int)M, dW, Cin, 0, 1));
+  c.e->pool.put(dYt);
   return 0;
 }
 
@@ -1533,6 +1781,175 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
   e->pool.put(xa); e->pool.put(xb);
   if (nz) e->pool.put(nz);
   return 0;
+}
+
+int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int B, int learn_sigma,
+                        const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* xt_next, float* x0_t,
+                        float* delta_h_out, float* middle_h, void* stream) {
+  TRY(check_ready(e, B));
+  if (!xt || !xt_next || !x0_t) return fail(ASYRP_EINVAL, "null tensor");
+  if (e->cfg.n_delta < 1) return fail(ASYRP_EINVAL, "no DeltaBlock (setattr_layers)");
+  if (!hs_coeff_host || n_coeff < 2) return fail(ASYRP_EINVAL, "hs_coeff needs 2 entries");
+  const asyrp_config& cf = e->cfg;
+  if (learn_sigma || cf.out_channels != 3 || cf.in_channels != 3) return fail(ASYRP_EINVAL, "training step expects a 3-channel eps network");
+  HIPCHK(hipSetDevice(e->device));
+  TRY(ensure_bwd_weights(e));
+  Ctx c{e, (hipStream_t)stream, B};
+  TRY(bind_stream(e, c.s));
+  // a previous tape that was never consumed is discarded
+  e->pool.release_held();
+  e->tape.clear();
+  struct Guard {   // on any exit: stop deferring; on failure also drop what was held
+    asyrp_engine* e; bool ok = false;
+    ~Guard() { e->pool.defer = false; if (!ok) { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); } }
+  } guard{e};
+  e->pool.defer = true;
+  c.tape = &e->tape;
+  e->tape.B = B;
+  const int HW = cf.resolution * cf.resolution;
+  float *xn, *xo, *x0o;
+  TRY(e->pool.get((size_t)B * HW * 3, &xn));
+  TRY(e->pool.get((size_t)B * HW * 3, &xo));
+  TRY(e->pool.get((size_t)B * HW * 3, &x0o));
+  HIPCHK(launch_nchw_to_nhwc(xt, xn, B, 3, HW, c.s));
+  hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+  Act a_et, a_em, a_dh, a_mid;
+  TRY(unet_core(c, xn, e->d_t, 0, 1, hs_coeff_host, ignore_timestep, &a_et, &a_em, &a_dh, &a_mid));
+  TRY(ddim_apply(c, xn, a_et, a_em, nullptr, t, t_next, 0.f, 1.f, 999, xo, x0o));
+  HIPCHK(launch_nhwc_to_nchw(xo, 3, xt_next, B, 3, HW, c.s));
+  HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0_t, B, 3, HW, c.s));
+  if (a_dh.p && delta_h_out) HIPCHK(launch_nhwc_to_nchw(a_dh.p, a_dh.C, delta_h_out, B, a_dh.C, a_dh.H * a_dh.W, c.s));
+  if (middle_h) HIPCHK(launch_nhwc_to_nchw(a_mid.p, a_mid.C, middle_h, B, a_mid.C, a_mid.H * a_mid.W, c.s));
+  drop(c, a_et);
+  if (a_em.p) drop(c, a_em);
+  if (a_dh.p) drop(c, a_dh);
+  drop(c, a_mid);
+  e->pool.put(xn); e->pool.put(xo); e->pool.put(x0o);
+  e->pool.defer = false;
+  e->pool.reclaim();          // (nothing should be live: every buffer was put -> held)
+  e->tape.valid = true;
+  guard.ok = true;
+  return 0;
+}
+
+int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, const char* const* keys, float* const* grads,
+                         void* stream) {
+  if (!e || !e->tape.valid) return fail(ASYRP_ESTATE, "asyrp_train_backward without a preceding asyrp_train_forward");
+  if (!d_et_mod || n_grads < 0 || (n_grads && (!keys || !grads))) return fail(ASYRP_EINVAL, "bad argument");
+  Tape& tp = e->tape;
+  const int B = tp.B;
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  TRY(bind_stream(e, c.s));
+  struct Guard {   // the tape is consumed whatever happens
+    asyrp_engine* e;
+    ~Guard() { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); }
+  } guard{e};
+  auto out_ptr = [&](const std::string& key) -> float* {
+    for (int i = 0; i < n_grads; ++i)
+      if (key == keys[i]) return grads[i];
+    return nullptr;
+  };
+  const asyrp_config& cf = e->cfg;
+  const int R = cf.resolution, HW = R * R;
+  // d(eps~) NCHW -> NHWC
+  Act g;
+  TRY(new_act(c, cf.out_channels, R, R, &g));
+  HIPCHK(launch_nchw_to_nhwc(d_et_mod, g.p, B, cf.out_channels, HW, c.s));
+  // conv_out^T, then norm_out + SiLU backward
+  Act dA, d;
+  TRY(conv_bwd_data(c, g, "conv_out.weight", tp.out_h.C, 3, nullptr, &dA));
+  drop(c, g);
+  TRY(act_gn_backward(c, dA, tp.out_h, nullptr, tp.out_sc, tp.out_sh, tp.out_mr, "norm_out", 1, tp.out_h.C, nullptr, &d));
+  drop(c, dA);
+  for (int k = (int)tp.order.size() - 1; k >= 0; --k) {
+    const TapeEntry& en = tp.order[k];
+    Act nd;
+    if (en.type == 0) {
+      TRY(resblock_backward(c, tp.res[en.idx], d, &nd));
+    } else if (en.type == 1) {
+      TRY(attnblock_backward(c, tp.attn[en.idx], d, &nd));
+    } else {
+      const TapeUp& u = tp.up[en.idx];     // y = conv3x3(nearest_x2(h)): transposed conv at the fine resolution, then 2x2 sums
+      Act fine;
+      TRY(conv_bwd_data(c, d, u.p + ".weight", u.C, 3, nullptr, &fine));
+      TRY(new_act(c, u.C, u.H, u.W, &nd));
+      HIPCHK(launch_sum2x2(fine.p, nd.p, B, u.H, u.W, u.C, c.s));
+      drop(c, fine);
+    }
+    drop(c, d);
+    d = nd;
+  }
+  // d = dL/dh2 [B, Rb, Rb, Cb];  h2 = c0*h + c1*Delta  ->  dDelta = c1 * d
+  const int Cb = tp.d_h.C, Mb = B * tp.d_h.H * tp.d_h.W, HWb = tp.d_h.H * tp.d_h.W;
+  Act dD;
+  TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &dD));
+  HIPCHK(launch_scale(d.p, tp.c1, dD.p, (long long)Mb * Cb, c.s));
+  drop(c, d);
+  // DeltaBlock (models/ddpm/diffusion.py:250-263): d1 = conv1(h) + temb_proj(swish(temb)); a = swish(GN(d1)); Delta = conv2(a)
+  Act a_act;
+  TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &a_act));
+  HIPCHK(launch_act_apply(tp.d_d1.p, tp.d_sc, tp.d_sh, 1, a_act.p, B, HWb, Cb, c.s));
+  if (float* o = out_ptr("layer_0.conv2.weight")) TRY(weight_grad(c, dD.p, Cb, a_act.p, Cb, Mb, o));
+  if (float* o = out_ptr("layer_0.conv2.bias")) HIPCHK(launch_colsum(dD.p, Cb, Mb, Cb, o, c.s));
+  drop(c, a_act);
+  Act da;
+  TRY(conv_bwd_data(c, dD, "layer_0.conv2.weight", Cb, 1, nullptr, &da));
+  drop(c, dD);
+  // GroupNorm + SiLU backward on d1, keeping the partial sums for the norm's own parameter gradients
+  {
+    const int nblk = act_bwd_nblk(HWb);
+    Act dy, d_d1;
+    float *part, *coef;
+    TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &dy));
+    TRY(e->pool.get((size_t)B * nblk * Cb * 4, &part));
+    TRY(e->pool.get((size_t)B * Cb * 3, &coef));
+    ActBwdArgs a;
+    memset(&a, 0, sizeof a);
+    a.dA = da.p; a.ldd = Cb; a.x0 = tp.d_d1.p; a.c0 = Cb; a.ldx0 = Cb; a.x0_z = tp.d_d1.per_image();
+    a.scale = tp.d_sc; a.shift = tp.d_sh; a.silu = 1; a.dy = dy.p; a.partial = reinterpret_cast<double*>(part);
+    a.HW = HWb; a.N = B; a.C = Cb;
+    HIPCHK(launch_act_bwd_partial(a, c.s));
+    float* dgam = out_ptr("layer_0.norm2.weight");
+    float* dbet = out_ptr("layer_0.norm2.bias");
+    if (dgam && dbet) HIPCHK(launch_gn_param_grad(a.partial, nblk, tp.d_mr, B, Cb, dgam, dbet, c.s));
+    GnBwdFinArgs f;
+    memset(&f, 0, sizeof f);
+    f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, "layer_0.norm2.weight"); f.mr = tp.d_mr; f.N = B; f.HW = HWb; f.C = Cb;
+    f.coef = coef;
+    HIPCHK(launch_gn_bwd_finalize(f, c.s));
+    TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &d_d1));
+    HIPCHK(launch_gn_bwd_apply(dy.p, Cb, tp.d_d1.p, Cb, tp.d_d1.per_image(), coef, nullptr, d_d1.p, Cb, HWb, B, c.s));
+    e->pool.put(part); e->pool.put(coef);
+    drop(c, dy);
+    drop(c, da);
+    if (float* o = out_ptr("layer_0.conv1.weight")) TRY(weight_grad(c, d_d1.p, Cb, tp.d_h.p, Cb, Mb, o));
+    if (float* o = out_ptr("layer_0.conv1.bias")) HIPCHK(launch_colsum(d_d1.p, Cb, Mb, Cb, o, c.s));
+    float* dtw = out_ptr("layer_0.temb_proj.weight");
+    float* dtb = out_ptr("layer_0.temb_proj.bias");
+    if (tp.d_temb) {
+      if (dtb) HIPCHK(launch_colsum(d_d1.p, Cb, Mb, Cb, dtb, c.s));
+      if (dtw) {   // d_tp[b][co] = sum_pix d_d1[b][pix][co];  dW[co][k] = sum_b d_tp[b][co] * swish(temb)[b][k]
+        float* dtp;
+        TRY(e->pool.get((size_t)B * Cb, &dtp));
+        for (int b = 0; b < B; ++b)
+          HIPCHK(launch_colsum(d_d1.p + (size_t)b * HWb * Cb, Cb, HWb, Cb, dtp + (size_t)b * Cb, c.s));
+        TRY(weight_grad(c, dtp, Cb, tp.temb_act, e->temb_ch, B, dtw));
+        e->pool.put(dtp);
+      }
+    } else {      // ignore_timestep: temb is None (:253-254), the projection does not take part
+      if (dtw) HIPCHK(hipMemsetAsync(dtw, 0, sizeof(float) * (size_t)Cb * e->temb_ch, c.s));
+      if (dtb) HIPCHK(hipMemsetAsync(dtb, 0, sizeof(float) * Cb, c.s));
+    }
+    drop(c, d_d1);
+  }
+  return 0;
+}
+
+void asyrp_train_discard(asyrp_engine* e) {
+  if (!e) return;
+  e->pool.release_held();
+  e->tape.clear();
 }
 
 // DDIM inversion with a per-step read-out: the engine half of the reference's LPIPS(t) table builder

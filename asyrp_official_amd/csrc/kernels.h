@@ -103,6 +103,7 @@ struct GnFin2Args {
   const float* gamma; const float* beta; float eps;
   const float* film_scale; const float* film_shift; int ld_film;
   float* scale; float* shift;               // [N][C0+C1]
+  float* mr;                                // nullable: [N][32][2] = (mean, rstd) of every group, kept for the backward pass
 };
 hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s);
 
@@ -152,5 +153,37 @@ struct DdimArgs {
   long long npix;                 // N*HW
 };
 hipError_t launch_ddim(const DdimArgs& a, hipStream_t s);
+
+// ---- training step (backward.hip): data gradients through decoder #2, DeltaBlock parameter gradients ----
+struct ActBwdArgs {
+  const float* dA; int ldd;                 // gradient w.r.t. act(GN(x)), [N][HW][ldd]
+  const float* x0; const float* x1; int c0, c1, ldx0, ldx1; long long x0_z, x1_z;   // forward input of the norm (virtual concat)
+  const float* scale; const float* shift;   // [N][C]: the forward's GroupNorm apply terms
+  int silu;                                 // act = SiLU (1) or identity (0: attention norm)
+  float* dy;                                // [N][HW][C]: dA * act'(y)
+  double* partial;                          // [N][act_bwd_nblk(HW)][C][2]: sum dy, sum dy*x
+  int HW, N, C;
+};
+int act_bwd_nblk(int HW);
+hipError_t launch_act_bwd_partial(const ActBwdArgs& a, hipStream_t s);
+struct GnBwdFinArgs {
+  const double* partial; int nblk;
+  const float* gamma; const float* mr;      // mr [N][32][2] from the forward finalize
+  int N, HW, C;
+  float* coef;                              // [N][C][3]: dx = coef0*dy + coef1*x + coef2
+};
+hipError_t launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
+hipError_t launch_gn_bwd_apply(const float* dy, int C, const float* x0, int ldx0, long long x0_z, const float* coef,
+                               const float* add, float* dx, int Cd, int HW, int N, hipStream_t s);
+hipError_t launch_sum2x2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_transpose(const float* in, int ldi, long long in_z, float* out, int R, int Ccols, long long out_z, int Z,
+                            hipStream_t s);
+hipError_t launch_softmax_bwd(const float* P, float* dP, long long rows, int T, float scale, hipStream_t s);
+hipError_t launch_colsum(const float* in, int ld, long long M, int C, float* out, hipStream_t s);
+hipError_t launch_act_apply(const float* x, const float* scale, const float* shift, int silu, float* out, int N, int HW, int C,
+                            hipStream_t s);
+hipError_t launch_gn_param_grad(const double* partial, int nblk, const float* mr, int N, int C, float* dgamma, float* dbeta,
+                                hipStream_t s);
+hipError_t launch_scale(const float* a, float sc, float* out, long long n, hipStream_t s);
 
 }  // namespace asyrp

@@ -571,6 +571,10 @@ __global__ void gn_finalize2_kernel(const GnFin2Args p) {
   double var = sm[0][1] / cnt - mean * mean;
   if (var < 0) var = 0;
   const double rstd = 1.0 / sqrt(var + (double)p.eps);
+  if (p.mr && tid == 0) {
+    p.mr[((size_t)n * 32 + g) * 2] = (float)mean;
+    p.mr[((size_t)n * 32 + g) * 2 + 1] = (float)rstd;
+  }
   if (tid < cg) {
     const int c = g * cg + tid;
     double sc = (double)p.gamma[c] * rstd;

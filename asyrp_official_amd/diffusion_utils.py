@@ -3,6 +3,7 @@ denoising_step :24-104) on top of the HIP engine's fused DDIM step (asyrp_ddim_s
 import numpy as np
 import torch
 
+from . import training
 from ._base import HipUNet
 
 
@@ -55,6 +56,12 @@ def denoising_step(xt, t, t_next, *, models, logvars=None, b, sampling_type='ddi
     eng = model._ready_engine(xt)
     ti, tn = _uniform_int(t, "t"), _uniform_int(t_next, "t_next")
     apply_edit = index is not None and ti >= t_edit
+    if training.wants_training(model, index, apply_edit):
+        # the reference's training loop (diffusion_latent.py:308-321, 349-350): gradients flow to the DeltaBlock only
+        if eta != 0 or delta_h is not None or dt_lambda != 1 or (index or 0) != 0:
+            raise NotImplementedError("the training step is the eta=0, single-DeltaBlock Asyrp step the reference trains with")
+        return training.train_step(model, xt.detach(), ti, tn, hs_coeff=hs_coeff, ignore_timestep=ignore_timestep,
+                                   learn_sigma=learn_sigma)
     if eta != 0 and noise is None:
         noise = torch.randn_like(xt)
     xt_next, x0_t, dh, mid = eng.ddim_step(xt, ti, tn, eta=float(eta), noise=noise if eta != 0 else None,

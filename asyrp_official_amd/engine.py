@@ -220,6 +220,34 @@ class Engine:
                                                     _ptr(x_last), self._stream()))
         return x_last, x_tap, x0t_tap
 
+    # ---- DeltaBlock training step (asyrp_train_forward / asyrp_train_backward) ----------------------
+    def train_forward(self, xt, t, t_next, *, hs_coeff=(1.0, 1.0), ignore_timestep=False, learn_sigma=False):
+        xt = self._image(xt, "xt")
+        B = xt.shape[0]
+        br, bc = self.bott_res, self.bott_ch
+        xn, x0t = torch.empty_like(xt), torch.empty_like(xt)
+        dh = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
+        mid = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
+        coeff, ncoeff = self._coeff(hs_coeff, 0)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_train_forward(self.h, _ptr(xt), int(t), int(t_next), B, int(bool(learn_sigma)), coeff,
+                                                    ncoeff, int(bool(ignore_timestep)), _ptr(xn), _ptr(x0t), _ptr(dh),
+                                                    _ptr(mid), self._stream()))
+        return xn, x0t, dh, mid
+
+    def train_backward(self, d_et_mod, named_shapes):
+        """d_et_mod [B,Cout,R,R]; named_shapes: [(state_dict key, shape)] of the DeltaBlock parameters -> list of gradients."""
+        d = _dev_f32(d_et_mod, "d_et_mod")
+        grads = [torch.empty(tuple(shape), device=d.device, dtype=torch.float32) for _, shape in named_shapes]
+        keys = (C.c_char_p * len(grads))(*[k.encode() for k, _ in named_shapes])
+        ptrs = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        with torch.cuda.device(self.device_index):
+            _lib.check(self.lib.asyrp_train_backward(self.h, _ptr(d), len(grads), keys, ptrs, self._stream()))
+        return grads
+
+    def train_discard(self):
+        self.lib.asyrp_train_discard(self.h)
+
     def get_temb(self, t):
         t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
         out = torch.empty((t.shape[0], self.cfg.ch * 4), device=t.device, dtype=torch.float32)

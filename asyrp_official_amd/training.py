@@ -1,0 +1,65 @@
+"""Training step of the DeltaBlock on the HIP engine (reference: diffusion_latent.py:282-354).
+
+The reference trains `layer_0` with
+    xt_next, x0_t, _, _ = denoising_step(xt_next.detach(), t=t, t_next=t_next, models=model, ..., index=0, t_edit=..., hs_coeff=...)
+    loss = l1_w * L1(x0_t, x0_t_origin) * cosine + clip_w * clip_direction_loss(x0, src, x0_t, trg)
+    loss.backward(); optim_ft.step()
+with `requires_grad` switched on for the DeltaBlock parameters only (:282-290).  Here the same lines keep working: when
+gradients are enabled and a DeltaBlock parameter requires grad, `asyrp_official_amd.denoising_step` routes the step through
+`AsyrpTrainStep`, an autograd node whose backward runs the engine's decoder-#2 backward pass (asyrp_train_backward) and hands
+autograd the gradients of the DeltaBlock parameters.  The loss (CLIP, L1, id) and the optimiser stay in PyTorch.
+"""
+import torch
+
+from .engine import alphas_cumprod_from_betas
+
+
+def delta_block_params(model, index=0):
+    """[(state_dict key, parameter)] of layer_{index}, in module order."""
+    layer = getattr(model, f"layer_{index}")
+    return [(f"layer_{index}.{k}", p) for k, p in layer.named_parameters()]
+
+
+def wants_training(model, index, apply_edit):
+    if not (torch.is_grad_enabled() and index is not None and apply_edit):
+        return False
+    return any(p.requires_grad for _, p in delta_block_params(model, index))
+
+
+class AsyrpTrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, xt, t, t_next, hs_coeff, ignore_timestep, learn_sigma, *params):
+        if learn_sigma:
+            raise NotImplementedError("the engine's training step covers the DDPM UNet family (eps-only output)")
+        eng = model._ready_engine(xt)                    # uploads whatever the optimiser changed since the last step
+        xt_next, x0_t, dh, mid = eng.train_forward(xt, t, t_next, hs_coeff=hs_coeff, ignore_timestep=ignore_timestep)
+        ab = alphas_cumprod_from_betas(model._betas)
+        at = float(ab[t])
+        at_next = 1.0 if t_next < 0 else float(ab[t_next])
+        ctx.eng = eng
+        ctx.named_shapes = [(k, tuple(p.shape)) for k, p in delta_block_params(model, 0)]
+        # x0_t = (xt - et_mod*sqrt(1-at))/sqrt(at);  xt_next = sqrt(at_next)*x0_t + sqrt(1-at_next)*et   (utils/diffusion_utils.py:85-92)
+        ctx.k_x0 = -((1.0 - at) ** 0.5) / (at ** 0.5)
+        ctx.k_xn = at_next ** 0.5
+        ctx.mark_non_differentiable(dh, mid)
+        return xt_next, x0_t, dh, mid
+
+    @staticmethod
+    def backward(ctx, g_xn, g_x0, _g_dh, _g_mid):
+        g = None
+        if g_x0 is not None:
+            g = g_x0
+        if g_xn is not None:
+            g = ctx.k_xn * g_xn if g is None else g + ctx.k_xn * g_xn
+        if g is None:
+            ctx.eng.train_discard()
+            return (None,) * 7 + (None,) * len(ctx.named_shapes)
+        grads = ctx.eng.train_backward((ctx.k_x0 * g).contiguous(), ctx.named_shapes)
+        return (None,) * 7 + tuple(grads)
+
+
+def train_step(model, xt, t, t_next, *, hs_coeff=(1.0, 1.0), ignore_timestep=False, learn_sigma=False):
+    """One differentiable Asyrp step: (xt_next, x0_t, delta_h, middle_h) with autograd edges to the DeltaBlock parameters."""
+    params = [p for _, p in delta_block_params(model, 0)]
+    return AsyrpTrainStep.apply(model, xt, int(t), int(t_next), tuple(float(v) for v in hs_coeff), bool(ignore_timestep),
+                                bool(learn_sigma), *params)

@@ -76,7 +76,7 @@ typedef struct asyrp_config {
 typedef struct asyrp_engine asyrp_engine;
 
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
-#define ASYRP_ABI_VERSION 5
+#define ASYRP_ABI_VERSION 6
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */
@@ -162,6 +162,25 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
  * (diffusion_latent.py:1239-1276); callers walk a long inversion in windows by restarting from the last tap. */
 int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv_host, int n_inv, int learn_sigma,
                         int tap_first, int tap_count, float* x_tap, float* x0t_tap, float* x_last, void* stream);
+
+/* ---- DeltaBlock training step (diffusion_latent.py:301-354), DDPM family, one DeltaBlock ----------------
+ * The reference trains layer_0 with `loss(x0_t).backward(); optim.step()` where x0_t comes from
+ * denoising_step(xt.detach(), ..., index=0, t_edit, hs_coeff) with gradients enabled on the DeltaBlock only
+ * (diffusion_latent.py:282-290, 308-321, 349-350).  The loss (CLIP direction + L1, :337-347) stays in the caller's PyTorch;
+ * the engine provides the step and the gradient of any such loss w.r.t. the DeltaBlock parameters:
+ *   asyrp_train_forward   = asyrp_ddim_step(eta = 0, index = 0, apply_edit = 1) that keeps decoder #2's activations;
+ *   asyrp_train_backward  takes dL/d(et_modified) [B,Cout,R,R] (the caller folds x0_t = (xt - et_mod*sqrt(1-a))/sqrt(a) and
+ *                         xt_next = sqrt(a')*x0_t + ... into it), back-propagates through decoder #2 (transposed
+ *                         convolutions on the same MFMA kernels; GroupNorm / SiLU / attention / upsample backward) to the
+ *                         bottleneck and writes the gradients of the named DeltaBlock parameters ("layer_0.conv1.weight",
+ *                         ... reference state_dict names and shapes) to the given DEVICE buffers.  Consumes the tape.
+ *   asyrp_train_discard   drops an unconsumed tape (e.g. a step whose loss is not back-propagated). */
+int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int B, int learn_sigma,
+                        const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* xt_next, float* x0_t,
+                        float* delta_h_out, float* middle_h, void* stream);
+int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, const char* const* keys, float* const* grads_dev,
+                         void* stream);
+void asyrp_train_discard(asyrp_engine* e);
 
 /* DDPM.get_temb (models/ddpm/diffusion.py:464-470): t [B] float timesteps (device) -> temb [B, 4*ch] (device).
  * For the iDDPM family: time_embed(timestep_embedding(t)) (models/improved_ddpm/unet.py:688). */

@@ -1,7 +1,9 @@
 """CPU experiment (not a test): how far does a split-precision MFMA conv drift from the fp32 oracle?
 
 Emulates  conv(x, w) ~= conv(x_hi, w_hi) + conv(x_hi, w_lo) + conv(x_lo, w_hi)  with x_hi/x_lo, w_hi/w_lo
-the two-term f16 (or bf16) split of the fp32 operands.  Products of two f16 values are exact in fp32,
+the two-term f16 (or bf16) split of the fp32 operands.  Modes: f32, f16x1, f16x3, bf16x1, bf16x3, and the round-2 candidates for
+cutting matrix work per output: f16x3-cross-e4m3 / f16x3-cross-e2m3 (cross terms on block-scaled fp8 / MX-fp6) and f16x3-wino
+(Winograd F(2x2,3x3) on the split, 2.25x fewer products).  Products of two f16 values are exact in fp32,
 and the CPU conv accumulates in fp32 like the matrix core does, so this is a faithful model of a
 v_mfma_f32_32x32x16_f16 "x3" implicit GEMM.  Run:  python tests/experiments/split_precision_numerics.py [mode]
 """
@@ -26,10 +28,75 @@ def split(v, dt, rtz=False):
     return hi, lo
 
 
+def q_block(v, fmt, dim, block=32):
+    """Block-scaled (MX-style: one power-of-two scale per `block` consecutive elements along `dim`) quantisation to fp8 e4m3
+    or to a 4-bit-significand fp6 (e2m3).  Emulates the operands of v_mfma_scale_f32_*_f8f6f4."""
+    v = v.movedim(dim, -1)
+    shp = v.shape
+    pad = (-shp[-1]) % block
+    if pad:
+        v = F.pad(v, (0, pad))
+    g = v.reshape(*v.shape[:-1], -1, block)
+    amax = g.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    if fmt == "e4m3":
+        sc = 2.0 ** torch.floor(torch.log2(256.0 / amax))            # block max lands in [256, 448]
+        q = (g * sc).to(torch.float8_e4m3fn).float() / sc
+    else:                                                             # e2m3: 1 sign, 2 exponent, 3 mantissa bits; max 7.5
+        sc = 2.0 ** torch.floor(torch.log2(4.0 / amax))
+        y = g * sc
+        e = torch.floor(torch.log2(y.abs().clamp_min(2.0 ** -1))).clamp(0, 2)   # normal binades 1..7.5, subnormal step 1/8
+        step = 2.0 ** (e - 3)
+        q = (torch.round(y / step) * step).clamp(-7.5, 7.5) / sc
+    q = q.reshape(*v.shape)[..., : shp[-1]]
+    return q.movedim(-1, dim)
+
+
+def winograd_f2x2_3x3(x, w, cross):
+    """F(2x2,3x3) Winograd on the f16 split: input/weight transforms in fp32, the 16 per-frequency channel contractions as
+    split products (3 per product, `cross` quantises the two cross terms), output transform in fp32."""
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    U = (G @ w.double() @ G.T).float()                               # [K, C, 4, 4]
+    xp = F.pad(x, (1, 1, 1, 1))
+    tiles = xp.unfold(2, 4, 2).unfold(3, 4, 2)                       # [N, C, H/2, W/2, 4, 4]
+    V = Bt @ tiles @ Bt.T
+    dt = torch.float16
+    s = 2.0 ** torch.floor(torch.log2(1.0 / U.abs().max())).item()
+    Vh, Vl = split(V, dt)
+    Uh, Ul = split(U * s, dt)
+    def prod(a, b):
+        return torch.einsum("nchwij,kcij->nkhwij", a, b)
+    M = prod(Vh, Uh) + (prod(cross(Vh, 1), cross(Ul, 1)) + prod(cross(Vl, 1), cross(Uh, 1)))
+    Y = At @ (M / s) @ At.T                                          # [N, K, H/2, W/2, 2, 2]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
+
+
 def conv_split(x, sd, p, stride=1, padding=0):
     w, b = sd[p + ".weight"], sd[p + ".bias"]
     if MODE == "f32":
         return F.conv2d(x, w, b, stride=stride, padding=padding)
+    if MODE.startswith("f16x3-cross-") or MODE == "f16x3-wino":
+        # x_hi*w_hi stays on the f16 MFMA; the two cross terms (each a 2^-11-relative correction) go to the 2x-rate fp8 or the
+        # 4x-rate MX-fp6 matrix instruction with block scales along K (VERDICT r01 item 3 candidate i), or the whole 3x3
+        # stride-1 conv goes through Winograd F(2x2,3x3) on the split (candidate ii)
+        fmt = MODE.rsplit("-", 1)[1]
+        s = 2.0 ** torch.floor(torch.log2(1.0 / w.abs().max())).item()
+        kw = dict(stride=stride, padding=padding)
+        ident = lambda v, dim: v
+        if MODE == "f16x3-wino":
+            if w.shape[2] == 3 and stride == 1 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                return winograd_f2x2_3x3(x, w, ident) + b[None, :, None, None]
+            cross = ident
+        else:
+            cross = lambda v, dim: q_block(v, fmt, dim)
+        xh, xl = split(x, torch.float16)
+        wh, wl = split(w * s, torch.float16)
+        y = F.conv2d(xh, wh, None, **kw) + (F.conv2d(cross(xh, 1), cross(wl, 1), None, **kw) +
+                                            F.conv2d(cross(xl, 1), cross(wh, 1), None, **kw))
+        return y / s + b[None, :, None, None]
     dt = torch.float16 if MODE.startswith("f16") else torch.bfloat16
     # per-layer power-of-two weight scale so the f16 lo term stays out of the subnormal range
     s = 2.0 ** torch.floor(torch.log2(1.0 / w.abs().max())).item() if MODE.startswith("f16") else 1.0

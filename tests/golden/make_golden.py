@@ -374,6 +374,31 @@ def run_config1(out, tame=1.0):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_config1_tame(out, tame=0.01):
+    """Config 1 with conv_out scaled by `tame`: the only change that makes the REFERENCE reproduce itself on a free-running
+    39+40 edit (measured with the reference on CPU: a 1-ulp change of x0 moves x_edit by 5.8e-2 at tame=1, 5.8e-2 at 0.25,
+    5.2e-4 at 0.05, 5.8e-5 at 0.02), so the engine's free-running x_T / x_edit can be held to rtol 1e-3 / atol 1e-4."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd = config1_state_dict(tame)
+    m = ref_model(CELEBA, sd, n_delta=1)
+    x = hash_uniform("config1.x0", (1, 3, 256, 256), seed=1234)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    seq, seq_next = _seq40()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim")
+    one = torch.ones(1)
+    g = {"tame": torch.tensor(float(tame))}
+    with torch.no_grad():
+        for i, j in zip(seq_next[1:], seq[1:]):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0, **kw)
+        g["x_T"] = x.clone()
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        g["x_edit"] = x.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_config3(out):
     """BASELINE config 3 (AFHQ-Dog iDDPM + the SHIPPED `dog_happy` DeltaBlock), generation phase from a seeded x_T through the
     REFERENCE: B=1, 40 Asyrp steps, learn_sigma, t_edit=444 (utils/t_edit_dic.py:5).  Stored: x_edit and steps at t=999,
@@ -416,6 +441,39 @@ def run_config3(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_train_small(out):
+    """Gradients of the DeltaBlock through the REFERENCE's own autograd (the training step of diffusion_latent.py:301-354 minus
+    the CLIP network): small DDPM, one Asyrp step with grad enabled on layer_0 only (:282-290), a fixed linear functional of
+    (x0_t, xt_next) as the loss, so dL/dx0_t and dL/dxt_next are known tensors."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(1)
+    cfg = SMALL
+    sd = synthetic_state_dict(ddpm_param_shapes(cfg, n_delta=2), seed=7)
+    m = ref_model(cfg, sd, n_delta=2)
+    B = 2
+    x = hash_normal("small.x", (B, 3, 32, 32), seed=1)
+    g1 = hash_normal("train.g_x0t", (B, 3, 32, 32), seed=3)
+    g2 = hash_normal("train.g_xtn", (B, 3, 32, 32), seed=4)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = {}
+    for tag, ign in (("step", False), ("ignoret", True)):
+        for p_ in m.parameters():
+            p_.requires_grad = False
+        for p_ in m.layer_0.parameters():
+            p_.requires_grad = True
+            p_.grad = None
+        xn, x0t, _, _ = denoising_step(x, t=torch.ones(B) * 701.0, t_next=torch.ones(B) * 675.0, models=m, logvars=np.zeros(1000),
+                                       b=betas, sampling_type="ddim", eta=0.0, index=0, t_edit=500, hs_coeff=(1.0, 0.8),
+                                       ignore_timestep=ign)
+        loss = (x0t * g1).sum() + (xn * g2).sum()
+        loss.backward()
+        g[f"{tag}.x0_t"], g[f"{tag}.xt_next"] = x0t.detach().clone(), xn.detach().clone()
+        for k, p_ in m.layer_0.named_parameters():
+            g[f"{tag}.grad.layer_0.{k}"] = (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -429,7 +487,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config3"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
@@ -447,5 +505,9 @@ if __name__ == "__main__":
         run_celeba(os.path.join(HERE, "ddpm_celeba.npz"))
     if a.only in (None, "config1"):
         run_config1(os.path.join(HERE, "config1_celeba_smiling.npz"))
+    if a.only in (None, "train"):
+        run_train_small(os.path.join(HERE, "train_small.npz"))
+    if a.only in (None, "config1_tame"):
+        run_config1_tame(os.path.join(HERE, "config1_celeba_tame.npz"))
     if a.only in (None, "config3"):
         run_config3(os.path.join(HERE, "config3_afhq_dog_happy.npz"))

@@ -256,3 +256,29 @@ def test_oracle_on_config1_steps_with_shipped_delta_block():
     xn, x0t, _, _ = sampler.denoising_step(g["eta153.x_t"], one * 153, one * 128, model=model, b=b, eta=1.0, index=0,
                                            t_edit=500, hs_coeff=(1.0, 1.0), noise=noise[0])
     assert_close(xn, g["eta153.xt_next"], what="eta xt_next", **loose)
+
+
+def test_oracle_autograd_matches_reference_autograd():
+    """The oracle is differentiable like the reference: DeltaBlock gradients of a fixed functional of (x0_t, xt_next) through
+    the oracle's forward equal the reference's own autograd (tests/golden/train_small.npz)."""
+    from conftest import load_golden
+    g = load_golden("train_small.npz")
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(ddpm_param_shapes(SMALL, n_delta=2), seed=7)
+    x = hash_normal("small.x", (2, 3, 32, 32), seed=1)
+    g1 = hash_normal("train.g_x0t", (2, 3, 32, 32), seed=3)
+    g2 = hash_normal("train.g_xtn", (2, 3, 32, 32), seed=4)
+    b = sampler.beta_schedule()
+    ab = sampler.alpha_bar(b)
+    for tag, ign in (("step", False), ("ignoret", True)):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("layer_0.")}
+        et, em, _, _ = ddpm_forward({**sd, **leaves}, SMALL, x, torch.ones(2) * 701.0, index=0, t_edit=500, hs_coeff=(1.0, 0.8),
+                                    ignore_timestep=ign)
+        xn, x0t = sampler.ddim_update(x, et, em, ab[701], ab[675])
+        ((x0t * g1).sum() + (xn * g2).sum()).backward()
+        assert_close(x0t, g[f"{tag}.x0_t"], what="x0_t", **TIGHT)
+        for k, v in leaves.items():
+            want = g[f"{tag}.grad.{k}"]
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            scale = float(want.abs().max())
+            assert_close(got, want, rtol=1e-4, atol=1e-5 * max(scale, 1e-30), what=f"{tag} grad {k}")
