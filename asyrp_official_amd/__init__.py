@@ -5,6 +5,8 @@ Host-side mirror of the reference interface for the accelerated path only:
   UNetModel, i_DDPM, ...    models/improved_ddpm/{unet,script_util}.py, models/guided_diffusion/{unet,script_util}.py
   denoising_step, ...       utils/diffusion_utils.py:5-109
   run_edit / run_edit_sharded   the loops at diffusion_latent.py:1034-1045 and :503-520
+  training.train_step           the DeltaBlock training step of diffusion_latent.py:301-354 (loss and optimiser stay in PyTorch)
+  GaussianDiffusion             p_sample / ddim_sample / ddim_reverse_sample of models/guided_diffusion/gaussian_diffusion.py
 All compute is in asyrp_official_amd/libasyrp_hip.so (C ABI: include/asyrp.h).
 """
 from .ddpm import DDPM  # noqa: F401
@@ -13,6 +15,8 @@ from .diffusion_utils import denoising_step, extract, get_beta_schedule  # noqa:
 from .engine import AsyrpDeviceError, Engine  # noqa: F401
 from .sampler import gather_shards, run_edit, run_edit_sharded, shard_bounds, timestep_seq  # noqa: F401
 from . import cache  # noqa: F401  (latent-cache / Δh-checkpoint formats, hs_coeff schedules)
+from . import training  # noqa: F401  (DeltaBlock training step: autograd node over asyrp_train_forward / _backward)
+from .gaussian_diffusion import GaussianDiffusion  # noqa: F401  (vendored p_sample / ddim_sample / ddim_reverse_sample signatures)
 
 __all__ = ["DDPM", "UNetModel", "create_model", "i_DDPM", "guided_Diffusion", "denoising_step", "extract", "get_beta_schedule", "run_edit", "run_edit_sharded",
-           "timestep_seq", "shard_bounds", "gather_shards", "Engine", "AsyrpDeviceError"]
+           "timestep_seq", "shard_bounds", "gather_shards", "Engine", "AsyrpDeviceError", "GaussianDiffusion", "training", "cache"]

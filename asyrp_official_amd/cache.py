@@ -119,9 +119,23 @@ def make_hs_coeff(n_train_step, n_test_step, hs_coeff_delta_h=1.0, hs_coeff_orig
     return tuple([1.0 * hs_coeff_origin_h] + [1.0 / n_attr ** 0.5 * scaling * c for c in coeffs])
 
 
-def delta_interpolation_coeffs(min_delta, max_delta, num_delta, hs_coeff_origin_h=1.0, scaling_factor=1.0):
-    """--delta_interpolation: one hs_coeff tuple per strength, linspace(min, max, num) (diffusion_latent.py:726-755)."""
-    return [(1.0 * hs_coeff_origin_h, float(d) * scaling_factor) for d in np.linspace(min_delta, max_delta, num_delta)]
+def delta_interpolation_coeffs(min_delta, max_delta, num_delta, hs_coeff=(1.0, 1.0), multiple_attr=False):
+    """--delta_interpolation: the list of hs_coeff tuples the reference builds from the BASE tuple `hs_coeff`
+    (= make_hs_coeff(...)), diffusion_latent.py:726-755:
+      single attribute (:742-751)   every element of the base tuple times val, then element 0 forced to 1.0;
+      --multiple_attr (:728-740)    needs exactly two DeltaBlocks: the num_delta^2 grid (1.0, v1*c1, v2*c2)."""
+    vals = np.linspace(min_delta, max_delta, num_delta).tolist()
+    base = list(hs_coeff)
+    if multiple_attr:
+        if len(base) != 3:
+            raise ValueError("delta_multiple_attr_interpolation is only supported for get_h_num == 2 (diffusion_latent.py:729)")
+        return [(1.0, v1 * base[1], v2 * base[2]) for v1 in vals for v2 in vals]
+    out = []
+    for v in vals:
+        t = [v * e for e in base]
+        t[0] = 1.0
+        out.append(tuple(t))
+    return out
 
 
 @torch.no_grad()

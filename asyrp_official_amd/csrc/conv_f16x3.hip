@@ -764,13 +764,11 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
 }
 
 // the 256x128 tile the big 3x3 layers run on: 8 waves (4 per SIMD with two workgroups per CU), plain per-tap loop.
+// A 512x128 tile with 16 waves (one workgroup per CU, one weight slice and one barrier domain for all 16) measured +4 % on
+// 128->128 @256 but -1 % on every other layer and -0.7 % on the whole edit (profiles/r02c_ab_*_tile16wave.txt): removed.
 // Interleaved A/B against the 4-wave software-pipelined tile: +6...12 % per layer, +5 % on the whole edit
 // (profiles/r01_conv_microbench_w8*.txt)
-int gemm_main_tile() {
-  // ASYRP_MAIN_TILE=7 selects the 16-wave 512x128 experiment (A/B only)
-  static const int t = [] { const char* e = getenv("ASYRP_MAIN_TILE"); return (e && atoi(e) == XT_512x128W16) ? XT_512x128W16 : XT_256x128W8; }();
-  return t;
-}
+int gemm_main_tile() { return XT_256x128W8; }
 
 // tile ids of the f16x3 family (GemmArgs.tile / profile variant).
 // The choice is a function of the LAYER SHAPE only: the workgroup count is priced at a nominal batch, never at the
@@ -811,7 +809,7 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   const int t = requested_tile_x(a);
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32 || t == XT_512x128W16) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -821,7 +819,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_512x128W16);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
@@ -829,7 +827,6 @@ int gemm_mblocks(const GemmArgs& a) {
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x32:
       bm = 256; break;
-    case XT_512x128W16: bm = 512; break;
     case XT_128x128: bm = 128; break;
     default: bm = 64;
   }
@@ -851,8 +848,9 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X64x64_3 = XCfg<2, 2, 1, 1, 3, 1, 3, 3>;      // 49 KB
   using X256x64_3 = XCfg<4, 1, 2, 2, 3, 1, 4>;
   using X256x128w8_3 = XCfg<4, 2, 2, 2, 3, 1>;
-  using X512x128w16_3 = XCfg<8, 2, 2, 2, 3, 1>;      // experiment: 16 waves share one weight slice and one barrier domain
-  using X256x32_3 = XCfg<4, 1, 2, 1, 3, 1, 2, 1>;     // conv_out (Cout = 3 / 6): 32-wide N tile, 6 MFMAs per wave per K-step
+  // conv_out (Cout = 3 / 6): 32-wide N tile, 3 taps per barrier (18 MFMAs per wave between barriers).  Interleaved A/B at
+  // B=32 (profiles/r02f_ab_convout.txt): 1 tap per barrier 564-638 us, 3 taps 536-554 us, 9 taps 602-608 us
+  using X256x32_3 = XCfg<4, 1, 2, 1, 3, 1, 2, 3>;
   using X64x128_3s2 = XCfg<2, 2, 1, 2, 3, 2, 4>;
   using X256x128_1 = XCfg<4, 1, 2, 4, 1, 1, 2>;
   using X128x128_1 = XCfg<2, 2, 2, 2, 1, 1, 4>;
@@ -877,7 +875,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
-    if (eff_tile_x(a) == XT_512x128W16) return launch_x<X512x128w16_3, true, false, false, true>(a, s);
     return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
@@ -890,7 +887,6 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_512x128W16: return launch_x<X512x128w16_3, true>(a, s);
     }
   } else {
     switch (tile) {

@@ -1609,6 +1609,17 @@ int asyrp_finalize_params(asyrp_engine* e) {
       if (isd(s.key)) TRY(upload(e, s.key, v));
     }
   }
+  // transposed images of the training step: the DeltaBlock's second conv changes at every optimiser step, the decoder's
+  // only when new base weights are loaded (then everything is rebuilt lazily by the next asyrp_train_forward)
+  if (e->bwd_weights) {
+    for (auto& s : e->specs)
+      if (s.shape.size() == 4 && isd(s.key) && (s.key.rfind("up.", 0) == 0 || s.key.rfind("conv_out.", 0) == 0)) e->bwd_weights = false;
+    if (e->bwd_weights && isd("layer_0.conv2.weight")) {
+      const ParamSpec& s2 = e->specs[e->spec_idx.at("layer_0.conv2.weight")];
+      const int cout = (int)s2.shape[0], cin = (int)s2.shape[1], k = (int)s2.shape[2];
+      TRY(add_bwd_weight(e, s2.key + "#T", transpose_conv_weight(hostp(e, s2.key), cout, cin, k), cin, cout, k));
+    }
+  }
   std::fill(e->dirty.begin(), e->dirty.end(), 0);
   e->finalized = true;
   return 0;

@@ -268,7 +268,7 @@ class Engine:
             return "attention", "asyrp::attn_f16x3_kernel (T=%d)" % (v - 200000)
         if fam == 1:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
-                    7: (8, 2, 2, 2), 12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
+                    12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
             return "f16x3", "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
         tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
         return "f32", "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))

@@ -474,6 +474,47 @@ def run_train_small(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_vendored_samplers(out):
+    """The vendored GaussianDiffusion samplers of the reference (models/guided_diffusion/gaussian_diffusion.py: p_mean_variance,
+    p_sample, ddim_sample, ddim_reverse_sample) driven by the reference's small UNets through a first-output adapter (the
+    vendored code expects model(x, t) -> tensor).  Deterministic calls only: eta = 0, and p_sample with its noise recorded."""
+    from models.guided_diffusion import gaussian_diffusion as gd
+    from utils.diffusion_utils import get_beta_schedule
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    torch.set_num_threads(1)
+    betas = get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)
+    g = {}
+    B = 2
+    fams = (("ddpm", ref_model(SMALL, synthetic_state_dict(ddpm_param_shapes(SMALL, n_delta=2), seed=7), n_delta=2),
+             hash_normal("small.x", (B, 3, 32, 32), seed=1), gd.ModelVarType.FIXED_LARGE),
+            ("iddpm", ref_iddpm(SMALL_I, synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11), 2),
+             hash_normal("ismall.x", (B, 3, 32, 32), seed=2), gd.ModelVarType.LEARNED_RANGE))
+    with torch.no_grad():
+        for name, m, x, vt in fams:
+            diff = gd.GaussianDiffusion(betas=betas, model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=vt,
+                                        loss_type=gd.LossType.MSE)
+            model = lambda x_, t_, **kw: m(x_, t_.float())[0]
+            for tv in (701, 0):
+                t = torch.full((B,), tv, dtype=torch.long)
+                g[f"{name}.t{tv}.model_out"] = model(x, t)
+                pm = diff.p_mean_variance(model, x, t, clip_denoised=True)
+                for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                    g[f"{name}.t{tv}.pmv.{k}"] = pm[k].clone()
+                pm = diff.p_mean_variance(model, x, t, clip_denoised=False)
+                g[f"{name}.t{tv}.pmv_noclip.mean"] = pm["mean"].clone()
+                torch.manual_seed(5)
+                z = torch.randn_like(x)
+                torch.manual_seed(5)
+                ps = diff.p_sample(model, x, t)
+                g[f"{name}.t{tv}.p_sample.noise"], g[f"{name}.t{tv}.p_sample.sample"] = z, ps["sample"].clone()
+                ds = diff.ddim_sample(model, x, t, clip_denoised=False, eta=0.0)
+                g[f"{name}.t{tv}.ddim.sample"], g[f"{name}.t{tv}.ddim.pred_xstart"] = ds["sample"].clone(), ds["pred_xstart"].clone()
+                rs = diff.ddim_reverse_sample(model, x, t, clip_denoised=False, eta=0.0)
+                g[f"{name}.t{tv}.ddim_reverse.sample"] = rs["sample"].clone()
+    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    print("wrote", out, sorted(g)[:6], "...", len(g), "tensors")
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -487,7 +528,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
@@ -505,6 +546,8 @@ if __name__ == "__main__":
         run_celeba(os.path.join(HERE, "ddpm_celeba.npz"))
     if a.only in (None, "config1"):
         run_config1(os.path.join(HERE, "config1_celeba_smiling.npz"))
+    if a.only in (None, "samplers"):
+        run_vendored_samplers(os.path.join(HERE, "vendored_samplers_small.npz"))
     if a.only in (None, "train"):
         run_train_small(os.path.join(HERE, "train_small.npz"))
     if a.only in (None, "config1_tame"):

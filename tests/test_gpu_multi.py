@@ -1,0 +1,56 @@
+"""RCCL path: only meaningful with >= 2 GPUs in the box; skipped on the 1-GPU test boxes.  The same sharding and
+gather logic is covered on CPU with gloo (tests/test_host_cpu.py) and on one GPU bitwise (tests/test_gpu_edit.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+need2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
+
+
+@need2
+def test_run_edit_sharded_over_rccl():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "multi_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MULTI_GPU_OK world=2 backend=nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@need2
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` (no launcher) re-executes itself under torch.distributed.run and reports n_gpus = 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["collective_backend"] == "nccl" and res["parity_check"]["batch_invariance_bitwise"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -88,14 +88,14 @@ def test_f16x3_narrow_tile_for_conv_out():
         assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out tile {tile} Cout {Cout}", **TIGHT)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
     """Force each compiled tile shape of the f16x3 family (256x128 4-wave, 128x128, 64x128, 64x64, 256x64, 256x128
     8-wave) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32 concatenated channels, 160 output
     channels (partial N tile)."""
-    if tile in (6, 7) and k == 1:
-        pytest.skip("the 8- and 16-wave tiles are compiled for 3x3 convolutions only")
+    if tile == 6 and k == 1:
+        pytest.skip("the 8-wave tile is compiled for 3x3 convolutions only")
     B, H, W = 2, 40, 24
     x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
     x1 = hash_normal(f"tile.x1.{k}", (B, 32, H, W)) * 3.0

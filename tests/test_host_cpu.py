@@ -235,3 +235,12 @@ def test_hs_coeff_schedules_match_reference_formulas():
     assert hc[0] == 1.0 and abs(hc[1] - 0.5 / 2 ** 0.5) < 1e-12 and abs(hc[2] - 1 / 2 ** 0.5) < 1e-12
     sw = cache.delta_interpolation_coeffs(-1.0, 1.0, 5)
     assert [c[1] for c in sw] == [-1.0, -0.5, 0.0, 0.5, 1.0] and all(c[0] == 1.0 for c in sw)
+    # base tuple with hs_coeff_origin_h != 1 and a scaled delta: every element times val, element 0 forced to 1.0 (:742-751)
+    sw = cache.delta_interpolation_coeffs(0.5, 1.5, 3, hs_coeff=cache.make_hs_coeff(40, 20, hs_coeff_delta_h=1.5, hs_coeff_origin_h=0.9))
+    assert sw == [(1.0, 1.5), (1.0, 3.0), (1.0, 4.5)]
+    # two attributes: the num_delta^2 grid (1.0, v1*c1, v2*c2) (:728-740)
+    base = cache.make_hs_coeff(40, 40, n_attr=2)
+    grid = cache.delta_interpolation_coeffs(0.0, 1.0, 2, hs_coeff=base, multiple_attr=True)
+    assert grid == [(1.0, 0.0, 0.0), (1.0, 0.0, base[2]), (1.0, base[1], 0.0), (1.0, base[1], base[2])]
+    with pytest.raises(ValueError):
+        cache.delta_interpolation_coeffs(0.0, 1.0, 2, hs_coeff=(1.0, 1.0), multiple_attr=True)
