@@ -244,3 +244,32 @@ def test_hs_coeff_schedules_match_reference_formulas():
     assert grid == [(1.0, 0.0, 0.0), (1.0, 0.0, base[2]), (1.0, base[1], 0.0), (1.0, base[1], base[2])]
     with pytest.raises(ValueError):
         cache.delta_interpolation_coeffs(0.0, 1.0, 2, hs_coeff=(1.0, 1.0), multiple_attr=True)
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "utils", "diffusion_utils.py")), reason="reference not on this box")
+def test_bench_cpu_baseline_uses_the_reference_when_importable():
+    """bench.py's cpu_baseline leg: kind == "reference" (the reference's own DDPM + denoising_step) when /root/reference is
+    importable, and that path computes the same step as the oracle port it falls back to on the GPU box."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from asyrp_official_amd import DDPM
+    from oracle import sampler as osamp
+    torch.manual_seed(1234)
+    m = DDPM(bench.celeba_namespace(), max_batch=1)
+    m.setattr_layers(1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    betas = osamp.beta_schedule()
+    kind, step = bench._cpu_step_fn(sd, betas, "ddpm", False)
+    assert kind == "reference"
+    x = 2 * torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(7)) - 1
+    one = torch.ones(1)
+    torch.set_num_threads(8)
+    got = step(x, one * 0.0, one * 25.0, eta=0)[0]
+    os.environ["ASYRP_REFERENCE"] = "/nonexistent"
+    try:
+        kind2, step2 = bench._cpu_step_fn(sd, betas, "ddpm", False)
+    finally:
+        del os.environ["ASYRP_REFERENCE"]
+    assert kind2 == "port"
+    want = step2(x, one * 0.0, one * 25.0, eta=0)[0]
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-6)
