@@ -101,7 +101,7 @@ __global__ void gn_bwd_finalize_kernel(const GnBwdFinArgs p) {
   double a = 0.0, b = 0.0;
   for (int j = 0; j < cg; ++j) {
     const int c = g * cg + j;
-    const double gam = (double)p.gamma[c];
+    const double gam = (double)p.gamma[c] * (p.film_scale ? 1.0 + (double)p.film_scale[(size_t)n * p.ld_film + c] : 1.0);
     double p1 = 0.0, p2 = 0.0;
     for (int k = tid; k < p.nblk; k += 256) {
       const double* q = p.partial + (((size_t)n * p.nblk + k) * p.C + c) * 2;
@@ -123,7 +123,7 @@ __global__ void gn_bwd_finalize_kernel(const GnBwdFinArgs p) {
   if (tid < cg) {
     const int c = g * cg + tid;
     float* dst = p.coef + ((size_t)n * p.C + c) * 3;
-    dst[0] = (float)(rstd * (double)p.gamma[c]);
+    dst[0] = (float)(rstd * (double)p.gamma[c] * (p.film_scale ? 1.0 + (double)p.film_scale[(size_t)n * p.ld_film + c] : 1.0));
     dst[1] = (float)(-rstd * rstd * S2 / m);
     dst[2] = (float)(-rstd * S1 / m + mean * rstd * rstd * S2 / m);
   }

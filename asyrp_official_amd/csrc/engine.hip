@@ -121,8 +121,12 @@ struct ProfRec {
 
 // ---- what the training forward keeps for the backward pass through decoder #2 and the DeltaBlock (DDPM family) ----
 struct TapeRes { std::string p; Act x0, x1; bool has_x1 = false; Act h1; float *sc1 = nullptr, *sh1 = nullptr, *mr1 = nullptr,
-                 *sc2 = nullptr, *sh2 = nullptr, *mr2 = nullptr; int Cout = 0; bool shortcut = false; };
-struct TapeAttn { std::string p; Act x, qkv; float *sc = nullptr, *sh = nullptr, *mr = nullptr, *P = nullptr; };
+                 *sc2 = nullptr, *sh2 = nullptr, *mr2 = nullptr; int Cout = 0; bool shortcut = false;
+                 // sub-module names (DDPM: norm1/conv1/norm2/conv2/nin_shortcut; iDDPM: in_layers.0/.2, out_layers.0/.3, skip_connection)
+                 const char *n1 = ".norm1", *c1 = ".conv1", *n2 = ".norm2", *c2 = ".conv2", *sk = ".nin_shortcut";
+                 int mode = 0;                                   // 2: iDDPM ResBlock(up=True): nearest x2 on both branches
+                 const float* film = nullptr; int ld_film = 0; };   // iDDPM: GN(h)*(1+scale)+shift, scale = film[n][c]
+struct TapeAttn { std::string p; Act x, qkv; float *sc = nullptr, *sh = nullptr, *mr = nullptr, *P = nullptr; int heads = 1; };
 struct TapeUp { std::string p; int C = 0, H = 0, W = 0; };
 struct TapeEntry { int type; int idx; };   // 0 ResnetBlock, 1 AttnBlock, 2 Upsample (forward order)
 struct Tape {
@@ -134,6 +138,7 @@ struct Tape {
   std::vector<TapeUp> up;
   Act out_h; float *out_sc = nullptr, *out_sh = nullptr, *out_mr = nullptr;      // norm_out input and its GroupNorm terms
   Act d_h, d_d1; float *d_sc = nullptr, *d_sh = nullptr, *d_mr = nullptr;        // DeltaBlock: bottleneck h, conv1 output
+  float *d_sc0 = nullptr, *d_sh0 = nullptr, *d_mr0 = nullptr;                    // iDDPM DeltaBlock: its first GroupNorm (on h)
   bool d_temb = true;
   float c1 = 1.f;
   float* temb_act = nullptr;            // swish(temb) [B][temb_ch]
@@ -890,8 +895,8 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
   const std::string& p = L.p;
   const int Cin = x0.C + (x1 ? x1->C : 0), Cout = L.cout;
   if (Cin != L.cin) return fail(ASYRP_EINVAL, "channel mismatch entering " + p);
-  float *sc1, *sh1, *sc2, *sh2;
-  TRY(gn(c, x0, x1, p + ".in_layers.0", EPS_I, &sc1, &sh1));
+  float *sc1, *sh1, *sc2, *sh2, *mr1 = nullptr, *mr2 = nullptr;
+  TRY(gn(c, x0, x1, p + ".in_layers.0", EPS_I, &sc1, &sh1, nullptr, nullptr, 0, c.tape ? &mr1 : nullptr));
   Act h1, xr;          // xr: the (pooled) input of the skip path when the block resamples
   bool own_xr = false;
   int rups = 0;
@@ -919,7 +924,20 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
   e->pool.put(sc1); e->pool.put(sh1);
   // h = GN(h) * (1 + scale) + shift, (scale, shift) = chunk(Linear(SiLU(emb)), 2)  (:290-294)
   const float* film = c.tproj + e->tproj_off.at(p);
-  TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, e->tproj_total));
+  TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, e->tproj_total, c.tape ? &mr2 : nullptr));
+  if (c.tape) {
+    if (L.mode == 1) return fail(ASYRP_EINVAL, "down-sampling ResBlock inside the decoder");
+    TapeRes t;
+    t.p = p; t.x0 = x0; t.has_x1 = (x1 != nullptr);
+    if (x1) t.x1 = *x1;
+    t.h1 = h1; t.sc1 = sc1; t.sh1 = sh1; t.mr1 = mr1; t.sc2 = sc2; t.sh2 = sh2; t.mr2 = mr2;
+    t.Cout = Cout; t.shortcut = (Cin != Cout); t.mode = L.mode;
+    t.n1 = ".in_layers.0"; t.c1 = ".in_layers.2"; t.n2 = ".out_layers.0"; t.c2 = ".out_layers.3"; t.sk = ".skip_connection";
+    t.film = film; t.ld_film = e->tproj_total;
+    c.tape->order.push_back({0, (int)c.tape->res.size()});
+    c.tape->res.push_back(t);
+    e->pool.put(mr1); e->pool.put(mr2);
+  }
   if (Cin != Cout) {   // 1x1 skip_connection (never combined with up/down in the reference's arch dicts)
     if (L.mode) return fail(ASYRP_EINVAL, "resampling ResBlock with a channel change is not part of any reference config");
     bool fused = false;
@@ -947,8 +965,8 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
 // -> Conv1d(C,C) -> + x
 int attnblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x, Act* out) {
   const std::string& p = L.p;
-  float *sc, *sh;
-  TRY(gn(c, x, nullptr, p + ".norm", EPS_I, &sc, &sh));
+  float *sc, *sh, *mr = nullptr, *Pk = nullptr;
+  TRY(gn(c, x, nullptr, p + ".norm", EPS_I, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
   Act qkv;
   TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
   c.e->pool.put(sc); c.e->pool.put(sh);
@@ -957,7 +975,14 @@ int attnblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x, Act* out) {
   const int heads = x.C / nhc;
   Act o;
   TRY(new_act(c, x.C, x.H, x.W, &o));
-  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, heads, 1.0f / std::sqrt((float)nhc), o.p));
+  TRY(attention_core(c, qkv.p, x.C, x.H * x.W, heads, 1.0f / std::sqrt((float)nhc), o.p, c.tape ? 1 : 0, c.tape ? &Pk : nullptr));
+  if (c.tape) {
+    TapeAttn t;
+    t.p = p; t.x = x; t.qkv = qkv; t.sc = sc; t.sh = sh; t.mr = mr; t.P = Pk; t.heads = heads;
+    c.tape->order.push_back({1, (int)c.tape->attn.size()});
+    c.tape->attn.push_back(t);
+    c.e->pool.put(mr);
+  }
   drop(c, qkv);
   TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr, &x, out,
            true));
@@ -967,13 +992,18 @@ int attnblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x, Act* out) {
 
 // DeltaBlock.forward (:835-853; use_scale_shift_norm=False): GN-SiLU-conv1x1, (+Linear(SiLU(emb))), GN-SiLU-conv1x1
 int deltablock_i(Ctx& c, const std::string& p, const Act& h, bool use_emb, Act* out) {
-  float *sc, *sh;
-  TRY(gn(c, h, nullptr, p + ".in_layers.0", EPS_I, &sc, &sh));
+  float *sc, *sh, *mr0 = nullptr, *mr = nullptr;
+  TRY(gn(c, h, nullptr, p + ".in_layers.0", EPS_I, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr0 : nullptr));
   Act d1;
   TRY(conv(c, h, nullptr, p + ".in_layers.2.weight", p + ".in_layers.2.bias", h.C, 1, 1, 0, sc, sh, 1,
            use_emb ? c.tproj + c.e->tproj_off.at(p) : nullptr, nullptr, &d1, true));
+  if (c.tape) { c.tape->d_sc0 = sc; c.tape->d_sh0 = sh; c.tape->d_mr0 = mr0; c.e->pool.put(mr0); }
   c.e->pool.put(sc); c.e->pool.put(sh);
-  TRY(gn(c, d1, nullptr, p + ".out_layers.0", EPS_I, &sc, &sh));
+  TRY(gn(c, d1, nullptr, p + ".out_layers.0", EPS_I, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
+  if (c.tape) {
+    c.tape->d_h = h; c.tape->d_d1 = d1; c.tape->d_sc = sc; c.tape->d_sh = sh; c.tape->d_mr = mr; c.tape->d_temb = use_emb;
+    c.e->pool.put(mr);
+  }
   TRY(conv(c, d1, nullptr, p + ".out_layers.3.weight", p + ".out_layers.3.bias", h.C, 1, 1, 0, sc, sh, 1, nullptr, nullptr, out));
   c.e->pool.put(sc); c.e->pool.put(sh);
   drop(c, d1);
@@ -1016,9 +1046,13 @@ int decoder_i(Ctx& c, const Act& hin, const std::vector<Act>& hs, Act* eps) {
     h = o;
     own = true;
   }
-  float *sc, *sh;
-  TRY(gn(c, h, nullptr, "out.0", EPS_I, &sc, &sh));
+  float *sc, *sh, *mr = nullptr;
+  TRY(gn(c, h, nullptr, "out.0", EPS_I, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
   TRY(conv(c, h, nullptr, "out.2.weight", "out.2.bias", e->cfg.out_channels, 3, 1, 0, sc, sh, 1, nullptr, nullptr, eps));
+  if (c.tape) {
+    c.tape->out_h = h; c.tape->out_sc = sc; c.tape->out_sh = sh; c.tape->out_mr = mr;
+    e->pool.put(mr);
+  }
   e->pool.put(sc); e->pool.put(sh);
   if (own) drop(c, h);
   return 0;
@@ -1042,6 +1076,9 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
                          c.s));
   HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
                             e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
+  c.tape = nullptr;
+  if (tape) tape->temb_act = temb_act;
   e->pool.put(temb);
   e->pool.put(temb_act);
   std::vector<Act> hs;
@@ -1065,6 +1102,8 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     std::vector<Act> deltas(index + 1);
     const float* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
+    if (tape && index != 0) return fail(ASYRP_EINVAL, "the training step supports one DeltaBlock (index 0)");
+    c.tape = tape;
     for (int i = 0; i <= index; ++i) {
       TRY(deltablock_i(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
       dptr[i] = deltas[i].p;
@@ -1074,7 +1113,9 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
     for (int i = 0; i < index; ++i) drop(c, deltas[i]);
     *last_delta = deltas[index];
+    if (tape) tape->c1 = coeff[1];
     TRY(decoder_i(c, h2, hs, et_mod));
+    c.tape = nullptr;
     drop(c, h2);
   }
   TRY(decoder_i(c, h, hs, et));
@@ -1270,19 +1311,29 @@ int add_bwd_weight(asyrp_engine* e, const std::string& name, const std::vector<f
   return 0;
 }
 
-// transposed images of every decoder convolution (+ the DeltaBlock's second conv); built on the first training call
+// which parameters take part in the backward pass: every convolution of the decoder and the DeltaBlock's own 1x1 convs
+bool is_bwd_weight(const asyrp_engine* e, const std::string& key) {
+  if (e->cfg.family == ASYRP_FAMILY_IDDPM)
+    return key.rfind("output_blocks.", 0) == 0 || key.rfind("out.2.", 0) == 0 || key == "layer_0.out_layers.3.weight" ||
+           key == "layer_0.in_layers.2.weight";
+  return key.rfind("up.", 0) == 0 || key.rfind("conv_out.", 0) == 0 || key == "layer_0.conv2.weight";
+}
+
+int build_bwd_weight(asyrp_engine* e, const ParamSpec& s) {
+  const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (s.shape.size() == 4) ? (int)s.shape[2] : 1;
+  return add_bwd_weight(e, s.key + "#T", transpose_conv_weight(hostp(e, s.key), cout, cin, k), cin, cout, k);
+}
+
+// transposed images of every decoder convolution (+ the DeltaBlock's convs); built on the first training call
 int ensure_bwd_weights(asyrp_engine* e) {
   if (e->bwd_weights) return 0;
-  if (e->cfg.family != ASYRP_FAMILY_DDPM) return fail(ASYRP_EINVAL, "the training step is implemented for the DDPM UNet family");
   HIPCHK(hipDeviceSynchronize());
   for (auto& s : e->specs) {
-    if (s.shape.size() != 4) continue;
-    const bool dec = s.key.rfind("up.", 0) == 0 || s.key.rfind("conv_out.", 0) == 0 || s.key == "layer_0.conv2.weight";
-    if (!dec) continue;
-    const int cout = (int)s.shape[0], cin = (int)s.shape[1], k = (int)s.shape[2];
+    if (!(s.shape.size() == 4 || s.shape.size() == 3) || !ends_with(s.key, ".weight") || !is_bwd_weight(e, s.key)) continue;
+    const int cout = (int)s.shape[0], cin = (int)s.shape[1];
     const std::string p = s.key.substr(0, s.key.size() - strlen(".weight"));
-    if (ends_with(p, ".k") || ends_with(p, ".v")) continue;
-    if (ends_with(p, ".q")) {   // fused q|k|v [3C][C] -> [C][3C]
+    if (e->cfg.family == ASYRP_FAMILY_DDPM && (ends_with(p, ".k") || ends_with(p, ".v"))) continue;
+    if (e->cfg.family == ASYRP_FAMILY_DDPM && ends_with(p, ".q")) {   // fused q|k|v [3C][C] -> [C][3C]
       const std::string ap = p.substr(0, p.size() - 2);
       std::vector<float> w3((size_t)3 * cout * cin);
       const char* names[3] = {".q", ".k", ".v"};
@@ -1293,7 +1344,7 @@ int ensure_bwd_weights(asyrp_engine* e) {
       TRY(add_bwd_weight(e, ap + ".qkv.weight#T", transpose_conv_weight(w3, 3 * cout, cin, 1), cin, 3 * cout, 1));
       continue;
     }
-    TRY(add_bwd_weight(e, s.key + "#T", transpose_conv_weight(hostp(e, s.key), cout, cin, k), cin, cout, k));
+    TRY(build_bwd_weight(e, s));
   }
   e->bwd_weights = true;
   return 0;
@@ -1301,7 +1352,8 @@ int ensure_bwd_weights(asyrp_engine* e) {
 
 // GroupNorm (+SiLU) backward of y = act(GN(x)) given dA = dL/dy: returns dx for the leading Cd channels of x (+ `add`)
 int act_gn_backward(Ctx& c, const Act& dA, const Act& x0, const Act* x1, const float* sc, const float* sh, const float* mr,
-                    const std::string& norm, int silu, int Cd, const Act* add, Act* dx) {
+                    const std::string& norm, int silu, int Cd, const Act* add, Act* dx, const float* film = nullptr,
+                    int ld_film = 0) {
   const int C = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W;
   if (dA.C != C) return fail(ASYRP_EINVAL, "gradient / activation channel mismatch at " + norm);
   Act dy;
@@ -1321,6 +1373,7 @@ int act_gn_backward(Ctx& c, const Act& dA, const Act& x0, const Act* x1, const f
   GnBwdFinArgs f;
   memset(&f, 0, sizeof f);
   f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, norm + ".weight"); f.mr = mr; f.N = c.B; f.HW = HW; f.C = C; f.coef = coef;
+  f.film_scale = film; f.ld_film = ld_film;
   if (!f.gamma) return fail(ASYRP_EKEY, "missing norm params " + norm);
   HIPCHK(launch_gn_bwd_finalize(f, c.s));
   TRY(new_act(c, Cd, x0.H, x0.W, dx));
@@ -1340,63 +1393,81 @@ int conv_bwd_data(Ctx& c, const Act& dY, const std::string& wname_fwd, int Cin_f
 int resblock_backward(Ctx& c, const TapeRes& t, const Act& d_out, Act* d_in) {
   const int Cin = t.x0.C + (t.has_x1 ? t.x1.C : 0), Ch = t.x0.C;
   Act dA2, d_h1, dA1;
-  TRY(conv_bwd_data(c, d_out, t.p + ".conv2.weight", t.Cout, 3, nullptr, &dA2));
-  TRY(act_gn_backward(c, dA2, t.h1, nullptr, t.sc2, t.sh2, t.mr2, t.p + ".norm2", 1, t.Cout, nullptr, &d_h1));
+  TRY(conv_bwd_data(c, d_out, t.p + t.c2 + ".weight", t.Cout, 3, nullptr, &dA2));
+  TRY(act_gn_backward(c, dA2, t.h1, nullptr, t.sc2, t.sh2, t.mr2, t.p + t.n2, 1, t.Cout, nullptr, &d_h1, t.film, t.ld_film));
   drop(c, dA2);
-  TRY(conv_bwd_data(c, d_h1, t.p + ".conv1.weight", Cin, 3, nullptr, &dA1));
+  TRY(conv_bwd_data(c, d_h1, t.p + t.c1 + ".weight", Cin, 3, nullptr, &dA1));
   drop(c, d_h1);
   Act d_short;
+  bool own_short = false;
   const Act* add = &d_out;     // identity shortcut: x + h
-  if (t.shortcut) {            // 1x1 nin_shortcut: only the gradient of the leading Ch input channels (the h part) is needed
-    TRY(conv_bwd_data(c, d_out, t.p + ".nin_shortcut.weight", Ch, 1, nullptr, &d_short, Cin));
+  if (t.mode == 2) {           // ResBlock(up=True): both branches went through nearest x2 -> 2x2 sums on the way back
+    if (t.shortcut || t.has_x1) return fail(ASYRP_EINVAL, "up-sampling ResBlock with a channel change");
+    Act lo;
+    TRY(new_act(c, Cin, t.x0.H, t.x0.W, &lo));
+    HIPCHK(launch_sum2x2(dA1.p, lo.p, c.B, t.x0.H, t.x0.W, Cin, c.s));
+    drop(c, dA1);
+    dA1 = lo;
+    TRY(new_act(c, Ch, t.x0.H, t.x0.W, &d_short));
+    HIPCHK(launch_sum2x2(d_out.p, d_short.p, c.B, t.x0.H, t.x0.W, Ch, c.s));
+    own_short = true;
+    add = &d_short;
+  } else if (t.shortcut) {     // 1x1 shortcut: only the gradient of the leading Ch input channels (the h part) is needed
+    TRY(conv_bwd_data(c, d_out, t.p + t.sk + ".weight", Ch, 1, nullptr, &d_short, Cin));
+    own_short = true;
     add = &d_short;
   } else if (Ch != t.Cout) {
     return fail(ASYRP_EINVAL, "identity shortcut with a channel change");
   }
-  TRY(act_gn_backward(c, dA1, t.x0, t.has_x1 ? &t.x1 : nullptr, t.sc1, t.sh1, t.mr1, t.p + ".norm1", 1, Ch, add, d_in));
+  TRY(act_gn_backward(c, dA1, t.x0, t.has_x1 ? &t.x1 : nullptr, t.sc1, t.sh1, t.mr1, t.p + t.n1, 1, Ch, add, d_in));
   drop(c, dA1);
-  if (t.shortcut) drop(c, d_short);
+  if (own_short) drop(c, d_short);
   return 0;
 }
 
-// one batched fp32-MFMA GEMM per image: out[z][m][n] = sum_k A[z][m][k] * B[z][k][n]  (bT: B[z][k][n] = Bt[z][n][k])
-int bgemm(Ctx& c, const float* A, int lda, long long a_z, const float* Bm, int ldb, long long b_z, int bT, int M, int N, int K,
-          float* out, int ldo, long long o_z, int Z) {
+// batched fp32-MFMA GEMM, z = (image, head): out[z][m][n] = sum_k A[z][m][k] * B[z][k][n]  (bT: B[z][k][n] = Bt[z][n][k])
+int bgemm(Ctx& c, const float* A, int lda, long long a_zo, long long a_zi, const float* Bm, int ldb, long long b_zo, long long b_zi,
+          int bT, int M, int N, int K, float* out, int ldo, long long o_zo, long long o_zi, int Zo, int ZI = 1) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
-  g.a0 = A; g.c0 = K; g.lda0 = lda; g.a0_zo = a_z;
+  g.a0 = A; g.c0 = K; g.lda0 = lda; g.a0_zo = a_zo; g.a0_zi = a_zi;
   g.Hin = M; g.Win = 1; g.Hout = M; g.Wout = 1; g.Cin = K; g.Cout = N; g.ks = 1; g.stride = 1;
-  g.w = Bm; g.ldb = ldb; g.bT = bT; g.w_zo = b_z;
-  g.alpha = 1.0f; g.out = out; g.ldo = ldo; g.o_zo = o_z; g.ZI = 1; g.Z = Z; g.math = MATH_F32;
+  g.w = Bm; g.ldb = ldb; g.bT = bT; g.w_zo = b_zo; g.w_zi = b_zi;
+  g.alpha = 1.0f; g.out = out; g.ldo = ldo; g.o_zo = o_zo; g.o_zi = o_zi; g.ZI = ZI; g.Z = Zo * ZI; g.math = MATH_F32;
   return run_gemm(c, g);
 }
 
+// AttnBlock (one C-wide head, q|k|v blocks) and AttentionBlock + QKVAttentionLegacy (heads of Dh channels, per-head [q|k|v])
 int attnblock_backward(Ctx& c, const TapeAttn& t, const Act& d_out, Act* d_in) {
-  const int C = t.x.C, T = t.x.H * t.x.W, B = c.B;
-  const float scale = 1.0f / std::sqrt((float)C);
+  const int C = t.x.C, T = t.x.H * t.x.W, B = c.B, H = t.heads, Dh = C / H;
+  const float scale = 1.0f / std::sqrt((float)Dh);
+  const bool iddpm = c.e->cfg.family == ASYRP_FAMILY_IDDPM;
   Act d_o;
   TRY(conv_bwd_data(c, d_out, t.p + ".proj_out.weight", C, 1, nullptr, &d_o));
-  const float* q = t.qkv.p; const float* k = t.qkv.p + C; const float* v = t.qkv.p + 2 * C;
-  const long long qz = (long long)T * 3 * C, tz = (long long)T * T;
+  const int q_off = 0, k_off = (H == 1) ? C : Dh, v_off = (H == 1) ? 2 * C : 2 * Dh;
+  const long long hs = (H == 1) ? 0 : 3 * Dh;            // head stride inside a qkv row
+  const float* q = t.qkv.p + q_off; const float* k = t.qkv.p + k_off; const float* v = t.qkv.p + v_off;
+  const long long qz = (long long)T * 3 * C, tz = (long long)T * T, oz = (long long)T * C;
   float *dP, *tr;
-  TRY(c.e->pool.get((size_t)B * T * T, &dP));
-  TRY(c.e->pool.get((size_t)B * T * T, &tr));
+  TRY(c.e->pool.get((size_t)B * H * T * T, &dP));
+  TRY(c.e->pool.get((size_t)B * H * T * T, &tr));
   Act dqkv;
   TRY(new_act(c, 3 * C, t.x.H, t.x.W, &dqkv));
   // dP = d_o V^T ; dS = P * (dP - rowsum(dP * P)) * scale
-  TRY(bgemm(c, d_o.p, C, (long long)T * C, v, 3 * C, qz, 1, T, T, C, dP, T, tz, B));
-  HIPCHK(launch_softmax_bwd(t.P, dP, (long long)B * T, T, scale, c.s));
+  TRY(bgemm(c, d_o.p, C, oz, Dh, v, 3 * C, qz, hs, 1, T, T, Dh, dP, T, H * tz, tz, B, H));
+  HIPCHK(launch_softmax_bwd(t.P, dP, (long long)B * H * T, T, scale, c.s));
   // dQ = dS K ; dK = dS^T Q ; dV = P^T d_o
-  TRY(bgemm(c, dP, T, tz, k, 3 * C, qz, 0, T, C, T, dqkv.p, 3 * C, qz, B));
-  HIPCHK(launch_transpose(dP, T, tz, tr, T, T, tz, B, c.s));
-  TRY(bgemm(c, tr, T, tz, q, 3 * C, qz, 0, T, C, T, dqkv.p + C, 3 * C, qz, B));
-  HIPCHK(launch_transpose(t.P, T, tz, tr, T, T, tz, B, c.s));
-  TRY(bgemm(c, tr, T, tz, d_o.p, C, (long long)T * C, 0, T, C, T, dqkv.p + 2 * C, 3 * C, qz, B));
+  TRY(bgemm(c, dP, T, H * tz, tz, k, 3 * C, qz, hs, 0, T, Dh, T, dqkv.p + q_off, 3 * C, qz, hs, B, H));
+  HIPCHK(launch_transpose(dP, T, tz, tr, T, T, tz, B * H, c.s));
+  TRY(bgemm(c, tr, T, H * tz, tz, q, 3 * C, qz, hs, 0, T, Dh, T, dqkv.p + k_off, 3 * C, qz, hs, B, H));
+  HIPCHK(launch_transpose(t.P, T, tz, tr, T, T, tz, B * H, c.s));
+  TRY(bgemm(c, tr, T, H * tz, tz, d_o.p, C, oz, Dh, 0, T, Dh, T, dqkv.p + v_off, 3 * C, qz, hs, B, H));
   c.e->pool.put(dP); c.e->pool.put(tr);
   drop(c, d_o);
   Act d_n;
   TRY(conv_bwd_data(c, dqkv, t.p + ".qkv.weight", C, 1, nullptr, &d_n));
   drop(c, dqkv);
+  (void)iddpm;
   TRY(act_gn_backward(c, d_n, t.x, nullptr, t.sc, t.sh, t.mr, t.p + ".norm", 0, C, &d_out, d_in));
   drop(c, d_n);
   return 0;
@@ -1407,7 +1478,7 @@ int weight_grad(Ctx& c, const float* dY, int Cout, const float* X, int Cin, long
   float* dYt;
   TRY(c.e->pool.get((size_t)Cout * M, &dYt));
   HIPCHK(launch_transpose(dY, Cout, 0, dYt, (int)M, Cout, 0, 1, c.s));
-  TRY(bgemm(c, dYt, (int)M, 0, X, Cin, 0, 0, Cout, Cin, (int)M, dW, Cin, 0, 1));
+  TRY(bgemm(c, dYt, (int)M, 0, 0, X, Cin, 0, 0, 0, Cout, Cin, (int)M, dW, Cin, 0, 0, 1));
   c.e->pool.put(dYt);
   return 0;
 }
@@ -1613,12 +1684,10 @@ int asyrp_finalize_params(asyrp_engine* e) {
   // only when new base weights are loaded (then everything is rebuilt lazily by the next asyrp_train_forward)
   if (e->bwd_weights) {
     for (auto& s : e->specs)
-      if (s.shape.size() == 4 && isd(s.key) && (s.key.rfind("up.", 0) == 0 || s.key.rfind("conv_out.", 0) == 0)) e->bwd_weights = false;
-    if (e->bwd_weights && isd("layer_0.conv2.weight")) {
-      const ParamSpec& s2 = e->specs[e->spec_idx.at("layer_0.conv2.weight")];
-      const int cout = (int)s2.shape[0], cin = (int)s2.shape[1], k = (int)s2.shape[2];
-      TRY(add_bwd_weight(e, s2.key + "#T", transpose_conv_weight(hostp(e, s2.key), cout, cin, k), cin, cout, k));
-    }
+      if (isd(s.key) && is_bwd_weight(e, s.key) && s.key.rfind("layer_0.", 0) != 0) e->bwd_weights = false;
+    if (e->bwd_weights)
+      for (auto& s : e->specs)
+        if (isd(s.key) && is_bwd_weight(e, s.key) && s.key.rfind("layer_0.", 0) == 0) TRY(build_bwd_weight(e, s));
   }
   std::fill(e->dirty.begin(), e->dirty.end(), 0);
   e->finalized = true;
@@ -1802,7 +1871,8 @@ int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int
   if (e->cfg.n_delta < 1) return fail(ASYRP_EINVAL, "no DeltaBlock (setattr_layers)");
   if (!hs_coeff_host || n_coeff < 2) return fail(ASYRP_EINVAL, "hs_coeff needs 2 entries");
   const asyrp_config& cf = e->cfg;
-  if (learn_sigma || cf.out_channels != 3 || cf.in_channels != 3) return fail(ASYRP_EINVAL, "training step expects a 3-channel eps network");
+  if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
+    return fail(ASYRP_EINVAL, "training step expects 3 image channels");
   HIPCHK(hipSetDevice(e->device));
   TRY(ensure_bwd_weights(e));
   Ctx c{e, (hipStream_t)stream, B};
@@ -1867,11 +1937,13 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
   Act g;
   TRY(new_act(c, cf.out_channels, R, R, &g));
   HIPCHK(launch_nchw_to_nhwc(d_et_mod, g.p, B, cf.out_channels, HW, c.s));
-  // conv_out^T, then norm_out + SiLU backward
+  // conv_out^T, then norm_out + SiLU backward  (iDDPM: out.2 / out.0)
+  const bool iddpm = cf.family == ASYRP_FAMILY_IDDPM;
   Act dA, d;
-  TRY(conv_bwd_data(c, g, "conv_out.weight", tp.out_h.C, 3, nullptr, &dA));
+  TRY(conv_bwd_data(c, g, iddpm ? "out.2.weight" : "conv_out.weight", tp.out_h.C, 3, nullptr, &dA));
   drop(c, g);
-  TRY(act_gn_backward(c, dA, tp.out_h, nullptr, tp.out_sc, tp.out_sh, tp.out_mr, "norm_out", 1, tp.out_h.C, nullptr, &d));
+  TRY(act_gn_backward(c, dA, tp.out_h, nullptr, tp.out_sc, tp.out_sh, tp.out_mr, iddpm ? "out.0" : "norm_out", 1, tp.out_h.C,
+                      nullptr, &d));
   drop(c, dA);
   for (int k = (int)tp.order.size() - 1; k >= 0; --k) {
     const TapeEntry& en = tp.order[k];
@@ -1897,15 +1969,21 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
   TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &dD));
   HIPCHK(launch_scale(d.p, tp.c1, dD.p, (long long)Mb * Cb, c.s));
   drop(c, d);
-  // DeltaBlock (models/ddpm/diffusion.py:250-263): d1 = conv1(h) + temb_proj(swish(temb)); a = swish(GN(d1)); Delta = conv2(a)
+  // DeltaBlock.  DDPM (models/ddpm/diffusion.py:250-263):   d1 = conv1(h) + temb_proj(swish(temb)); a = swish(GN(d1)); Delta = conv2(a)
+  //             iDDPM (models/improved_ddpm/unet.py:835-853): d1 = conv1(swish(GN0(h))) + emb_layers(emb);   a = swish(GN(d1)); Delta = conv2(a)
+  const char* k_c1 = iddpm ? "layer_0.in_layers.2" : "layer_0.conv1";
+  const char* k_c2 = iddpm ? "layer_0.out_layers.3" : "layer_0.conv2";
+  const char* k_n2 = iddpm ? "layer_0.out_layers.0" : "layer_0.norm2";
+  const char* k_tp = iddpm ? "layer_0.emb_layers.1" : "layer_0.temb_proj";
+  auto K = [](const char* a, const char* b) { return std::string(a) + b; };
   Act a_act;
   TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &a_act));
   HIPCHK(launch_act_apply(tp.d_d1.p, tp.d_sc, tp.d_sh, 1, a_act.p, B, HWb, Cb, c.s));
-  if (float* o = out_ptr("layer_0.conv2.weight")) TRY(weight_grad(c, dD.p, Cb, a_act.p, Cb, Mb, o));
-  if (float* o = out_ptr("layer_0.conv2.bias")) HIPCHK(launch_colsum(dD.p, Cb, Mb, Cb, o, c.s));
+  if (float* o = out_ptr(K(k_c2, ".weight"))) TRY(weight_grad(c, dD.p, Cb, a_act.p, Cb, Mb, o));
+  if (float* o = out_ptr(K(k_c2, ".bias"))) HIPCHK(launch_colsum(dD.p, Cb, Mb, Cb, o, c.s));
   drop(c, a_act);
   Act da;
-  TRY(conv_bwd_data(c, dD, "layer_0.conv2.weight", Cb, 1, nullptr, &da));
+  TRY(conv_bwd_data(c, dD, K(k_c2, ".weight"), Cb, 1, nullptr, &da));
   drop(c, dD);
   // GroupNorm + SiLU backward on d1, keeping the partial sums for the norm's own parameter gradients
   {
@@ -1921,23 +1999,49 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
     a.scale = tp.d_sc; a.shift = tp.d_sh; a.silu = 1; a.dy = dy.p; a.partial = reinterpret_cast<double*>(part);
     a.HW = HWb; a.N = B; a.C = Cb;
     HIPCHK(launch_act_bwd_partial(a, c.s));
-    float* dgam = out_ptr("layer_0.norm2.weight");
-    float* dbet = out_ptr("layer_0.norm2.bias");
+    float* dgam = out_ptr(K(k_n2, ".weight"));
+    float* dbet = out_ptr(K(k_n2, ".bias"));
     if (dgam && dbet) HIPCHK(launch_gn_param_grad(a.partial, nblk, tp.d_mr, B, Cb, dgam, dbet, c.s));
     GnBwdFinArgs f;
     memset(&f, 0, sizeof f);
-    f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, "layer_0.norm2.weight"); f.mr = tp.d_mr; f.N = B; f.HW = HWb; f.C = Cb;
+    f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, K(k_n2, ".weight")); f.mr = tp.d_mr; f.N = B; f.HW = HWb; f.C = Cb;
     f.coef = coef;
     HIPCHK(launch_gn_bwd_finalize(f, c.s));
     TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &d_d1));
     HIPCHK(launch_gn_bwd_apply(dy.p, Cb, tp.d_d1.p, Cb, tp.d_d1.per_image(), coef, nullptr, d_d1.p, Cb, HWb, B, c.s));
-    e->pool.put(part); e->pool.put(coef);
     drop(c, dy);
     drop(c, da);
-    if (float* o = out_ptr("layer_0.conv1.weight")) TRY(weight_grad(c, d_d1.p, Cb, tp.d_h.p, Cb, Mb, o));
-    if (float* o = out_ptr("layer_0.conv1.bias")) HIPCHK(launch_colsum(d_d1.p, Cb, Mb, Cb, o, c.s));
-    float* dtw = out_ptr("layer_0.temb_proj.weight");
-    float* dtb = out_ptr("layer_0.temb_proj.bias");
+    // conv1's input: h itself (DDPM) or swish(GN0(h)) (iDDPM)
+    if (iddpm) {
+      Act a0;
+      TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &a0));
+      HIPCHK(launch_act_apply(tp.d_h.p, tp.d_sc0, tp.d_sh0, 1, a0.p, B, HWb, Cb, c.s));
+      if (float* o = out_ptr(K(k_c1, ".weight"))) TRY(weight_grad(c, d_d1.p, Cb, a0.p, Cb, Mb, o));
+      drop(c, a0);
+      // GN0 parameter gradients: dA0 = conv1^T(d_d1), then the partial sums of dA0 * swish'(GN0(h)) against h
+      float* dg0 = out_ptr("layer_0.in_layers.0.weight");
+      float* db0 = out_ptr("layer_0.in_layers.0.bias");
+      if (dg0 && db0) {
+        Act dA0, dy0;
+        TRY(conv_bwd_data(c, d_d1, K(k_c1, ".weight"), Cb, 1, nullptr, &dA0));
+        TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &dy0));
+        ActBwdArgs a2;
+        memset(&a2, 0, sizeof a2);
+        a2.dA = dA0.p; a2.ldd = Cb; a2.x0 = tp.d_h.p; a2.c0 = Cb; a2.ldx0 = Cb; a2.x0_z = tp.d_h.per_image();
+        a2.scale = tp.d_sc0; a2.shift = tp.d_sh0; a2.silu = 1; a2.dy = dy0.p; a2.partial = reinterpret_cast<double*>(part);
+        a2.HW = HWb; a2.N = B; a2.C = Cb;
+        HIPCHK(launch_act_bwd_partial(a2, c.s));
+        HIPCHK(launch_gn_param_grad(a2.partial, nblk, tp.d_mr0, B, Cb, dg0, db0, c.s));
+        drop(c, dA0);
+        drop(c, dy0);
+      }
+    } else {
+      if (float* o = out_ptr(K(k_c1, ".weight"))) TRY(weight_grad(c, d_d1.p, Cb, tp.d_h.p, Cb, Mb, o));
+    }
+    e->pool.put(part); e->pool.put(coef);
+    if (float* o = out_ptr(K(k_c1, ".bias"))) HIPCHK(launch_colsum(d_d1.p, Cb, Mb, Cb, o, c.s));
+    float* dtw = out_ptr(K(k_tp, ".weight"));
+    float* dtb = out_ptr(K(k_tp, ".bias"));
     if (tp.d_temb) {
       if (dtb) HIPCHK(launch_colsum(d_d1.p, Cb, Mb, Cb, dtb, c.s));
       if (dtw) {   // d_tp[b][co] = sum_pix d_d1[b][pix][co];  dW[co][k] = sum_b d_tp[b][co] * swish(temb)[b][k]

@@ -169,6 +169,7 @@ hipError_t launch_act_bwd_partial(const ActBwdArgs& a, hipStream_t s);
 struct GnBwdFinArgs {
   const double* partial; int nblk;
   const float* gamma; const float* mr;      // mr [N][32][2] from the forward finalize
+  const float* film_scale; int ld_film;     // iDDPM FiLM: the forward applied gamma*(1 + film_scale[n][c]); null otherwise
   int N, HW, C;
   float* coef;                              // [N][C][3]: dx = coef0*dy + coef1*x + coef2
 };

@@ -540,10 +540,13 @@ hipError_t launch_gn_partial(const float* a, int lda, long long a_z, int HW, int
   return hipGetLastError();
 }
 
-// one workgroup per (group, image): fixed-order strided accumulation + fixed-order tree => deterministic
-__global__ void gn_finalize2_kernel(const GnFin2Args p) {
-  __shared__ double sm[256][2];
-  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+// one WAVE per (group, image): lane-strided accumulation in a fixed order + a fixed butterfly => deterministic and
+// batch-invariant; no LDS, no barriers (the kernel is launched 220 times per UNet evaluation: its cost is its latency)
+__global__ void __launch_bounds__(256) gn_finalize2_kernel(const GnFin2Args p) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);     // (image, group) pair
+  if (item >= p.N * 32) return;
+  const int n = item >> 5, g = item & 31;
   const int C = p.C0 + p.C1, cg = C / 32;
   double a = 0.0, b = 0.0;
   // items of this group: (channel j in [0,cg), block k) of the source the channel lives in
@@ -553,30 +556,28 @@ __global__ void gn_finalize2_kernel(const GnFin2Args p) {
     int nblk, Cs, cl;
     if (c < p.C0) { src = p.p0; nblk = p.nblk0; Cs = p.C0; cl = c; }
     else { src = p.p1; nblk = p.nblk1; Cs = p.C1; cl = c - p.C0; }
-    for (int k = tid; k < nblk; k += 256) {
+    for (int k = lane; k < nblk; k += 64) {
       const double* q = src + (((size_t)n * nblk + k) * Cs + cl) * 2;
       a += q[0];
       b += q[1];
     }
   }
-  sm[tid][0] = a;
-  sm[tid][1] = b;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) { sm[tid][0] += sm[tid + o][0]; sm[tid][1] += sm[tid + o][1]; }
-    __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
   }
   const double cnt = (double)cg * p.HW;
-  const double mean = sm[0][0] / cnt;
-  double var = sm[0][1] / cnt - mean * mean;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
   if (var < 0) var = 0;
   const double rstd = 1.0 / sqrt(var + (double)p.eps);
-  if (p.mr && tid == 0) {
+  if (p.mr && lane == 0) {
     p.mr[((size_t)n * 32 + g) * 2] = (float)mean;
     p.mr[((size_t)n * 32 + g) * 2 + 1] = (float)rstd;
   }
-  if (tid < cg) {
-    const int c = g * cg + tid;
+  for (int j = lane; j < cg; j += 64) {
+    const int c = g * cg + j;
     double sc = (double)p.gamma[c] * rstd;
     double sh = (double)p.beta[c] - mean * sc;
     if (p.film_scale) {   // h = GN(h)*(1+scale)+shift  (models/improved_ddpm/unet.py:290-294)
@@ -591,8 +592,8 @@ __global__ void gn_finalize2_kernel(const GnFin2Args p) {
 
 hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s) {
   const int C = a.C0 + a.C1;
-  if (C % 32 != 0 || C / 32 > 256 || !a.p0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(32, a.N), dim3(256), 0, s, a);
+  if (C % 32 != 0 || !a.p0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3((a.N * 32 + 3) / 4), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -643,13 +644,16 @@ hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s) {
 // =====================================================================================================
 // timestep embedding MLP (models/ddpm/diffusion.py:42-60, :477-480; improved_ddpm/nn.py:103-121)
 // =====================================================================================================
-__global__ void temb_mlp_kernel(const float* t, const float* freqs, int half, int sin_first, const float* w0,
+// grid (B, TEMB_SLICES): every workgroup evaluates the (cheap) first layer for its image, then its slice of the second layer's
+// rows; one wave per output row with coalesced weight reads (the weights are re-read per image from L2)
+constexpr int TEMB_SLICES = 8;
+__global__ void __launch_bounds__(256) temb_mlp_kernel(const float* t, const float* freqs, int half, int sin_first, const float* w0,
                                 const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
                                 float* temb_act) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];   // emb[ch] + h0[temb_ch]
   float* emb = tsm;
   float* h0 = tsm + ch;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float tv = t[b];
   for (int i = tid; i < ch; i += blockDim.x) {
     float v = 0.f;
@@ -662,20 +666,28 @@ __global__ void temb_mlp_kernel(const float* t, const float* freqs, int half, in
     emb[i] = v;
   }
   __syncthreads();
-  for (int j = tid; j < temb_ch; j += blockDim.x) {
+  for (int j = wave; j < temb_ch; j += 4) {
     const float* wr = w0 + (size_t)j * ch;
     float acc = 0.f;
-    for (int i = 0; i < ch; ++i) acc = fmaf(wr[i], emb[i], acc);
-    h0[j] = silu_f(acc + b0[j]);
+    for (int i = lane; i < ch; i += 64) acc = fmaf(wr[i], emb[i], acc);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+    if (lane == 0) h0[j] = silu_f(acc + b0[j]);
   }
   __syncthreads();
-  for (int j = tid; j < temb_ch; j += blockDim.x) {
+  const int per = (temb_ch + TEMB_SLICES - 1) / TEMB_SLICES;
+  const int j0 = blockIdx.y * per, j1 = min(temb_ch, j0 + per);
+  for (int j = j0 + wave; j < j1; j += 4) {
     const float* wr = w1 + (size_t)j * temb_ch;
     float acc = 0.f;
-    for (int i = 0; i < temb_ch; ++i) acc = fmaf(wr[i], h0[i], acc);
-    const float v = acc + b1[j];
-    temb[(size_t)b * temb_ch + j] = v;
-    temb_act[(size_t)b * temb_ch + j] = silu_f(v);
+    for (int i = lane; i < temb_ch; i += 64) acc = fmaf(wr[i], h0[i], acc);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+    if (lane == 0) {
+      const float v = acc + b1[j];
+      temb[(size_t)b * temb_ch + j] = v;
+      temb_act[(size_t)b * temb_ch + j] = silu_f(v);
+    }
   }
 }
 
@@ -683,33 +695,31 @@ hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin
                            const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
                            float* temb_act, int B, hipStream_t s) {
   const size_t sm = (size_t)(ch + temb_ch) * sizeof(float);
-  hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), sm, s, t, freqs, half, sin_first, w0, b0, w1, b1, ch,
+  hipLaunchKernelGGL(temb_mlp_kernel, dim3(B, TEMB_SLICES), dim3(256), sm, s, t, freqs, half, sin_first, w0, b0, w1, b1, ch,
                      temb_ch, temb, temb_act);
   return hipGetLastError();
 }
 
-// out[b][o] = sum_i W[o][i] * x[b][i] + bias[o]; one wave per output row, all images
+// out[b][o] = sum_i W[o][i] * x[b][i] + bias[o]; one wave per (image, output row)
 __global__ void linear_rows_kernel(const float* x, int ldx, const float* W, const float* bias, int I, int O,
                                    float* out, int ldo, int B) {
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
   if (o >= O) return;
   const float* wr = W + (size_t)o * I;
-  const float bo = bias ? bias[o] : 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* xr = x + (size_t)b * ldx;
-    float acc = 0.f;
-    for (int i = lane; i < I; i += 64) acc = fmaf(wr[i], xr[i], acc);
+  const float* xr = x + (size_t)b * ldx;
+  float acc = 0.f;
+  for (int i = lane; i < I; i += 64) acc = fmaf(wr[i], xr[i], acc);
 #pragma unroll
-    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
-    if (lane == 0) out[(size_t)b * ldo + o] = acc + bo;
-  }
+  for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+  if (lane == 0) out[(size_t)b * ldo + o] = acc + (bias ? bias[o] : 0.f);
 }
 
 hipError_t launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, int I, int O, float* out,
                               int ldo, int B, hipStream_t s) {
   const int wpb = 4;
-  hipLaunchKernelGGL(linear_rows_kernel, dim3((O + wpb - 1) / wpb), dim3(wpb * 64), 0, s, x, ldx, W, bias, I, O, out,
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((O + wpb - 1) / wpb, B), dim3(wpb * 64), 0, s, x, ldx, W, bias, I, O, out,
                      ldo, B);
   return hipGetLastError();
 }

@@ -29,10 +29,10 @@ def wants_training(model, index, apply_edit):
 class AsyrpTrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, xt, t, t_next, hs_coeff, ignore_timestep, learn_sigma, *params):
-        if learn_sigma:
-            raise NotImplementedError("the engine's training step covers the DDPM UNet family (eps-only output)")
         eng = model._ready_engine(xt)                    # uploads whatever the optimiser changed since the last step
-        xt_next, x0_t, dh, mid = eng.train_forward(xt, t, t_next, hs_coeff=hs_coeff, ignore_timestep=ignore_timestep)
+        xt_next, x0_t, dh, mid = eng.train_forward(xt, t, t_next, hs_coeff=hs_coeff, ignore_timestep=ignore_timestep,
+                                                   learn_sigma=learn_sigma)
+        ctx.out_channels = eng.out_channels
         ab = alphas_cumprod_from_betas(model._betas)
         at = float(ab[t])
         at_next = 1.0 if t_next < 0 else float(ab[t_next])
@@ -54,7 +54,11 @@ class AsyrpTrainStep(torch.autograd.Function):
         if g is None:
             ctx.eng.train_discard()
             return (None,) * 7 + (None,) * len(ctx.named_shapes)
-        grads = ctx.eng.train_backward((ctx.k_x0 * g).contiguous(), ctx.named_shapes)
+        d_em = (ctx.k_x0 * g).contiguous()
+        if ctx.out_channels != d_em.shape[1]:            # learn_sigma: eps = the first 3 of 6 output channels (diffusion_utils.py:47-51)
+            pad = torch.zeros((d_em.shape[0], ctx.out_channels - d_em.shape[1]) + tuple(d_em.shape[2:]), device=d_em.device)
+            d_em = torch.cat([d_em, pad], dim=1).contiguous()
+        grads = ctx.eng.train_backward(d_em, ctx.named_shapes)
         return (None,) * 7 + tuple(grads)
 
 

@@ -163,7 +163,7 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
 int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv_host, int n_inv, int learn_sigma,
                         int tap_first, int tap_count, float* x_tap, float* x0t_tap, float* x_last, void* stream);
 
-/* ---- DeltaBlock training step (diffusion_latent.py:301-354), DDPM family, one DeltaBlock ----------------
+/* ---- DeltaBlock training step (diffusion_latent.py:301-354), both UNet families, one DeltaBlock --------
  * The reference trains layer_0 with `loss(x0_t).backward(); optim.step()` where x0_t comes from
  * denoising_step(xt.detach(), ..., index=0, t_edit, hs_coeff) with gradients enabled on the DeltaBlock only
  * (diffusion_latent.py:282-290, 308-321, 349-350).  The loss (CLIP direction + L1, :337-347) stays in the caller's PyTorch;

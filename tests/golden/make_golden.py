@@ -470,6 +470,23 @@ def run_train_small(out):
         g[f"{tag}.x0_t"], g[f"{tag}.xt_next"] = x0t.detach().clone(), xn.detach().clone()
         for k, p_ in m.layer_0.named_parameters():
             g[f"{tag}.grad.layer_0.{k}"] = (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
+    # the iDDPM family (learn_sigma, FiLM ResBlocks with up-sampling, multi-head legacy attention, iDDPM DeltaBlock)
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    mi = ref_iddpm(SMALL_I, synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11), 2)
+    xi = hash_normal("ismall.x", (B, 3, 32, 32), seed=2)
+    for tag, ign in (("istep", False), ("iignoret", True)):
+        for p_ in mi.parameters():
+            p_.requires_grad = False
+        for p_ in mi.layer_0.parameters():
+            p_.requires_grad = True
+            p_.grad = None
+        xn, x0t, _, _ = denoising_step(xi, t=torch.ones(B) * 701.0, t_next=torch.ones(B) * 675.0, models=mi, logvars=np.zeros(1000),
+                                       b=betas, sampling_type="ddim", eta=0.0, learn_sigma=True, index=0, t_edit=500,
+                                       hs_coeff=(1.0, 0.8), ignore_timestep=ign)
+        ((x0t * g1).sum() + (xn * g2).sum()).backward()
+        g[f"{tag}.x0_t"], g[f"{tag}.xt_next"] = x0t.detach().clone(), xn.detach().clone()
+        for k, p_ in mi.layer_0.named_parameters():
+            g[f"{tag}.grad.layer_0.{k}"] = (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
     np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 

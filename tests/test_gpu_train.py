@@ -141,3 +141,32 @@ def test_unconsumed_tape_is_released():
         cur = eng.device_bytes()
         assert base is None or cur == base, "workspace grows across abandoned training steps"
         base = cur
+
+
+@pytest.mark.parametrize("conv_math", ["f16x3", "f32"])
+@pytest.mark.parametrize("tag,ign", [("istep", False), ("iignoret", True)])
+def test_iddpm_train_step_gradients_vs_reference_autograd(conv_math, tag, ign):
+    """The iDDPM / ADM family (models/improved_ddpm/unet.py): learn_sigma output, FiLM ResBlocks incl. the up-sampling ones,
+    multi-head legacy attention, the iDDPM DeltaBlock (two GroupNorms, emb_layers) -- gradients vs the reference's autograd."""
+    from asyrp_official_amd import denoising_step
+    from oracle.iddpm import SMALL_I, iddpm_param_shapes
+    from oracle.weights import synthetic_state_dict
+    from test_gpu_iddpm import hip_iddpm
+    g = load_golden("train_small.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11)
+    m = hip_iddpm(SMALL_I, sd, 2, conv_math=conv_math)
+    _enable_delta_grads(m)
+    x = hash_normal("ismall.x", (2, 3, 32, 32), seed=2).cuda()
+    g1 = hash_normal("train.g_x0t", (2, 3, 32, 32), seed=3).cuda()
+    g2 = hash_normal("train.g_xtn", (2, 3, 32, 32), seed=4).cuda()
+    b = osamp.beta_schedule().cuda()
+    one = torch.ones(2, device="cuda")
+    xn, x0t, dh, _ = denoising_step(x, t=one * 701.0, t_next=one * 675.0, models=m, logvars=None, b=b, sampling_type="ddim",
+                                    eta=0.0, learn_sigma=True, index=0, t_edit=500, hs_coeff=(1.0, 0.8), ignore_timestep=ign)
+    assert x0t.requires_grad and tuple(x0t.shape) == (2, 3, 32, 32)
+    assert_close(x0t, g[f"{tag}.x0_t"], what="x0_t")
+    assert_close(xn, g[f"{tag}.xt_next"], what="xt_next")
+    ((x0t * g1).sum() + (xn * g2).sum()).backward()
+    for k, p in m.layer_0.named_parameters():
+        assert p.grad is not None, k
+        assert_grad_close(p.grad, g[f"{tag}.grad.layer_0.{k}"], f"[iDDPM {conv_math}/{tag}] d loss / d layer_0.{k}")

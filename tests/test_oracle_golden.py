@@ -282,3 +282,28 @@ def test_oracle_autograd_matches_reference_autograd():
             got = v.grad if v.grad is not None else torch.zeros_like(v)
             scale = float(want.abs().max())
             assert_close(got, want, rtol=1e-4, atol=1e-5 * max(scale, 1e-30), what=f"{tag} grad {k}")
+
+
+def test_iddpm_oracle_autograd_matches_reference_autograd():
+    from conftest import load_golden
+    from oracle.iddpm import SMALL_I, iddpm_forward, iddpm_param_shapes
+    g = load_golden("train_small.npz")
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(iddpm_param_shapes(SMALL_I, n_delta=2), seed=11)
+    x = hash_normal("ismall.x", (2, 3, 32, 32), seed=2)
+    g1 = hash_normal("train.g_x0t", (2, 3, 32, 32), seed=3)
+    g2 = hash_normal("train.g_xtn", (2, 3, 32, 32), seed=4)
+    b = sampler.beta_schedule()
+    ab = sampler.alpha_bar(b)
+    for tag, ign in (("istep", False), ("iignoret", True)):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("layer_0.")}
+        et, em, _, _ = iddpm_forward({**sd, **leaves}, SMALL_I, x, torch.ones(2) * 701.0, index=0, t_edit=500, hs_coeff=(1.0, 0.8),
+                                     ignore_timestep=ign)
+        xn, x0t = sampler.ddim_update(x, et[:, :3], em[:, :3], ab[701], ab[675])
+        ((x0t * g1).sum() + (xn * g2).sum()).backward()
+        assert_close(x0t, g[f"{tag}.x0_t"], what="x0_t", rtol=1e-5, atol=2e-6 * float(g[f"{tag}.x0_t"].abs().max()))
+        for k, v in leaves.items():
+            want = g[f"{tag}.grad.{k}"]
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            scale = float(want.abs().max())
+            assert_close(got, want, rtol=1e-4, atol=1e-5 * max(scale, 1e-30), what=f"{tag} grad {k}")
