@@ -700,6 +700,22 @@ int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float ep
   return 0;
 }
 
+// every block's Linear(swish(temb)) at once: [B x temb_ch] x [temb_ch x O_total] + bias on the fp32-MFMA GEMM (exact fp32 fma
+// chain per output), one launch per UNet evaluation
+int tproj_gemm(Ctx& c, const float* temb_act) {
+  asyrp_engine* e = c.e;
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = temb_act; g.c0 = e->temb_ch; g.lda0 = e->temb_ch;
+  g.Hin = c.B; g.Win = 1; g.Hout = c.B; g.Wout = 1; g.Cin = e->temb_ch; g.Cout = e->tproj_total; g.ks = 1; g.stride = 1;
+  g.w = P(c, "__tproj.weight"); g.ldb = e->temb_ch; g.bT = 1;      // W is [O_total][temb_ch]
+  g.bias = P(c, "__tproj.bias");
+  g.alpha = 1.0f; g.out = c.tproj; g.ldo = e->tproj_total; g.ZI = 1; g.Z = 1; g.math = MATH_F32;
+  g.tile = TILE_64x64;          // fixed: the rows are the batch, so the tile must not depend on M
+  if (!g.w || !g.bias) return fail(ASYRP_EKEY, "missing timestep projection pack");
+  return run_gemm(c, g);
+}
+
 // ResnetBlock (models/ddpm/diffusion.py:151-170) on the virtual concat (x0|x1)
 int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* out) {
   asyrp_engine* e = c.e;
@@ -1074,8 +1090,7 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 0, P(c, "time_embed.0.weight"), P(c, "time_embed.0.bias"),
                          P(c, "time_embed.2.weight"), P(c, "time_embed.2.bias"), cf.ch, e->temb_ch, temb, temb_act, c.B,
                          c.s));
-  HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
-                            e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  TRY(tproj_gemm(c, temb_act));
   Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;
@@ -1150,8 +1165,7 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 1, P(c, "temb.dense.0.weight"), P(c, "temb.dense.0.bias"),
                          P(c, "temb.dense.1.weight"), P(c, "temb.dense.1.bias"), cf.ch, e->temb_ch, temb, temb_act,
                          c.B, c.s));
-  HIPCHK(launch_linear_rows(temb_act, e->temb_ch, P(c, "__tproj.weight"), P(c, "__tproj.bias"), e->temb_ch,
-                            e->tproj_total, c.tproj, e->tproj_total, c.B, c.s));
+  TRY(tproj_gemm(c, temb_act));
   Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;

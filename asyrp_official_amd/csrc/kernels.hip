@@ -644,16 +644,13 @@ hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s) {
 // =====================================================================================================
 // timestep embedding MLP (models/ddpm/diffusion.py:42-60, :477-480; improved_ddpm/nn.py:103-121)
 // =====================================================================================================
-// grid (B, TEMB_SLICES): every workgroup evaluates the (cheap) first layer for its image, then its slice of the second layer's
-// rows; one wave per output row with coalesced weight reads (the weights are re-read per image from L2)
-constexpr int TEMB_SLICES = 8;
-__global__ void __launch_bounds__(256) temb_mlp_kernel(const float* t, const float* freqs, int half, int sin_first, const float* w0,
+__global__ void temb_mlp_kernel(const float* t, const float* freqs, int half, int sin_first, const float* w0,
                                 const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
                                 float* temb_act) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];   // emb[ch] + h0[temb_ch]
   float* emb = tsm;
   float* h0 = tsm + ch;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float tv = t[b];
   for (int i = tid; i < ch; i += blockDim.x) {
     float v = 0.f;
@@ -666,28 +663,20 @@ __global__ void __launch_bounds__(256) temb_mlp_kernel(const float* t, const flo
     emb[i] = v;
   }
   __syncthreads();
-  for (int j = wave; j < temb_ch; j += 4) {
+  for (int j = tid; j < temb_ch; j += blockDim.x) {
     const float* wr = w0 + (size_t)j * ch;
     float acc = 0.f;
-    for (int i = lane; i < ch; i += 64) acc = fmaf(wr[i], emb[i], acc);
-#pragma unroll
-    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
-    if (lane == 0) h0[j] = silu_f(acc + b0[j]);
+    for (int i = 0; i < ch; ++i) acc = fmaf(wr[i], emb[i], acc);
+    h0[j] = silu_f(acc + b0[j]);
   }
   __syncthreads();
-  const int per = (temb_ch + TEMB_SLICES - 1) / TEMB_SLICES;
-  const int j0 = blockIdx.y * per, j1 = min(temb_ch, j0 + per);
-  for (int j = j0 + wave; j < j1; j += 4) {
+  for (int j = tid; j < temb_ch; j += blockDim.x) {
     const float* wr = w1 + (size_t)j * temb_ch;
     float acc = 0.f;
-    for (int i = lane; i < temb_ch; i += 64) acc = fmaf(wr[i], h0[i], acc);
-#pragma unroll
-    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
-    if (lane == 0) {
-      const float v = acc + b1[j];
-      temb[(size_t)b * temb_ch + j] = v;
-      temb_act[(size_t)b * temb_ch + j] = silu_f(v);
-    }
+    for (int i = 0; i < temb_ch; ++i) acc = fmaf(wr[i], h0[i], acc);
+    const float v = acc + b1[j];
+    temb[(size_t)b * temb_ch + j] = v;
+    temb_act[(size_t)b * temb_ch + j] = silu_f(v);
   }
 }
 
@@ -695,7 +684,7 @@ hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin
                            const float* b0, const float* w1, const float* b1, int ch, int temb_ch, float* temb,
                            float* temb_act, int B, hipStream_t s) {
   const size_t sm = (size_t)(ch + temb_ch) * sizeof(float);
-  hipLaunchKernelGGL(temb_mlp_kernel, dim3(B, TEMB_SLICES), dim3(256), sm, s, t, freqs, half, sin_first, w0, b0, w1, b1, ch,
+  hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), sm, s, t, freqs, half, sin_first, w0, b0, w1, b1, ch,
                      temb_ch, temb, temb_act);
   return hipGetLastError();
 }
