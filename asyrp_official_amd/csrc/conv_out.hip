@@ -1,0 +1,226 @@
+// conv_out.hip — the last convolution of the UNets (conv_out 128 -> 3, models/ddpm/diffusion.py:426-430,575-578; iDDPM out.2
+// 128 -> 6, models/improved_ddpm/unet.py:654-658), fused with its GroupNorm-apply + SiLU prologue.
+//
+// On the implicit-GEMM tiles this layer pads its 3 (6) output channels to a 32-wide N tile and pays 9 taps x Cin of matrix work
+// for them: 10x the useful products, which made an HBM-sized layer MFMA-bound (0.58-0.64 ms per launch at B = 32 against a
+// 0.2 ms HBM floor).  Here the taps move into N instead:
+//     Z[p][tap*Cout + co] = sum_ci act(x)[p][ci] * w[co][ci][tap]        one 1x1 GEMM, N = 9*Cout = 27 <= 32, K = Cin
+//     y[q][co]            = bias[co] + sum_tap Z[q + offset(tap)][tap*Cout + co]        a 9-term stencil over the halo pixels
+// so the matrix work drops 6.5x (f16x3 split products as everywhere else): 365 us instead of 587 us per launch at B = 32
+// (rocprofv3, same box).  The 6-channel iDDPM head needs two N tiles and measured equal to the tile path, which it keeps.
+// One workgroup = an 8 x 16 output patch of one image (10 x 18 halo pixels = 6 MFMA row tiles), 4 waves; the whole weight image
+// (<= 32 KB) sits in LDS for the launch; Z goes through LDS (aliasing the staging buffers) for the stencil.
+#include "kernels.h"
+
+namespace asyrp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CO_PH = 8, CO_PW = 16, CO_TH = CO_PH + 2, CO_TW = CO_PW + 2, CO_NPIX = CO_TH * CO_TW;   // 180 halo pixels
+constexpr int CO_MT = (CO_NPIX + 31) / 32;                                                             // 6 row tiles
+constexpr float CO_HMAX = 65504.0f;
+
+__device__ __forceinline__ float co_silu(float v) {
+  const float e = __expf(-v);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ void co_split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 s;
+    s[0] = __builtin_amdgcn_fmed3f(v[j], -CO_HMAX, CO_HMAX);
+    s[1] = __builtin_amdgcn_fmed3f(v[j + 1], -CO_HMAX, CO_HMAX);
+    const h2 h = __builtin_convertvector(s, h2);
+    f2 r;
+    r[0] = s[0] - (float)h[0];
+    r[1] = s[1] - (float)h[1];
+    const h2 l = __builtin_convertvector(r, h2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
+
+// TN = N tiles of 32 columns (9*Cout <= 32*TN).  Weight image = launch_pack_f16x3 of the equivalent 1x1 conv
+// w1[n = tap*Cout + co][ci]: [chunk][unit 4][cout_pad][8 halfs].
+template <int TN>
+__global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
+  constexpr int NT = 256, NW = 4, BN = 32 * TN;
+  constexpr int A_BYTES = CO_NPIX * 64;                 // [4 units][NPIX][16 B]
+  constexpr int ZLD = BN + 1;                           // padded row of the Z tile (floats)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch = p.Cin >> 4;
+  const int W_BYTES = nch * 4 * BN * 16;
+  char* const Ws = smem;                                // [chunk][4][BN][16 B]
+  char* const As = smem + W_BYTES;                      // 2 x A_BYTES
+  float* const Zs = reinterpret_cast<float*>(smem);     // after the K loop: [CO_MT*32][ZLD] floats (aliases Ws / As)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zo = blockIdx.z;
+  const int tiles_x = (p.Wout + CO_PW - 1) / CO_PW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * CO_PH, ox0 = tx * CO_PW;
+  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
+  const float* __restrict__ ps = p.pscale + (long long)zo * p.Cin;
+  const float* __restrict__ psh = p.pshift + (long long)zo * p.Cin;
+
+  // ---- weights -> LDS (once) ----
+  {
+    const char* wpk = reinterpret_cast<const char*>(p.wpk);
+    for (int i = tid; i < nch * 4 * BN; i += NT) {
+      const int n = i % BN, cu = i / BN;                 // cu = chunk*4 + unit
+      *reinterpret_cast<float4*>(Ws + (size_t)i * 16) = *reinterpret_cast<const float4*>(wpk + ((size_t)cu * p.cout_pad + n) * 16);
+    }
+  }
+  // ---- staging map: work item = (halo pixel, 8-channel half) ----
+  constexpr int NU = CO_NPIX * 2, NA = (NU + NT - 1) / NT;
+  const int hf = tid & 1;
+  int aoff[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tid + i * NT, pix = u >> 1;
+    int off = -2;
+    if (u < NU) {
+      const int iy = pix / CO_TW, ix = pix - iy * CO_TW;
+      const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+      off = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+    }
+    aoff[i] = off;
+  }
+  float4 areg[NA][2];
+  auto gload = [&](int chunk) {
+    const float* base = a0 + chunk * 16 + hf * 8;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (aoff[i] >= 0) {
+        const float* src = base + (long long)aoff[i] * p.lda0;
+        v0 = *reinterpret_cast<const float4*>(src);
+        v1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      areg[i][0] = v0;
+      areg[i][1] = v1;
+    }
+  };
+  auto stage = [&](int chunk, int buf) {
+    const int c = chunk * 16 + hf * 8;
+    const float4 s0 = *reinterpret_cast<const float4*>(ps + c), s1 = *reinterpret_cast<const float4*>(ps + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(psh + c), h1 = *reinterpret_cast<const float4*>(psh + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (aoff[i] == -2) continue;
+      float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w, areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      if (aoff[i] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = co_silu(__builtin_fmaf(t[j], sc[j], sh[j]));
+      }
+      h8 hi, lo;
+      co_split8(t, hi, lo);
+      const int pix = (tid + i * NT) >> 1;
+      char* dst = As + buf * A_BYTES + (hf * CO_NPIX + pix) * 16;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + 2 * CO_NPIX * 16) = lo;
+    }
+  };
+
+  // ---- MFMA rows: wave w owns row tiles {w, w + 4} (< CO_MT); A-fragment row = halo pixel (clamped for the padding rows) ----
+  const int kh = lane >> 5;
+  constexpr int TMW = (CO_MT + NW - 1) / NW;            // 2
+  int arow[TMW];
+#pragma unroll
+  for (int t = 0; t < TMW; ++t) arow[t] = min((wave + NW * t) * 32 + (lane & 31), CO_NPIX - 1);
+  f32x16 acc[TMW][TN];
+#pragma unroll
+  for (int t = 0; t < TMW; ++t)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
+
+  gload(0);
+  stage(0, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const bool more = chunk + 1 < nch;
+    if (more) gload(chunk + 1);
+    const char* A = As + (chunk & 1) * A_BYTES + kh * CO_NPIX * 16;
+    const char* B = Ws + ((size_t)chunk * 4 + kh) * BN * 16 + (lane & 31) * 16;
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+      if (wave + NW * t >= CO_MT) continue;             // wave-uniform
+      const h8 ah = *reinterpret_cast<const h8*>(A + arow[t] * 16);
+      const h8 al = *reinterpret_cast<const h8*>(A + arow[t] * 16 + 2 * CO_NPIX * 16);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const h8 bh = *reinterpret_cast<const h8*>(B + n * 32 * 16);
+        const h8 bl = *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][n], 0, 0, 0);
+      }
+    }
+    if (more) stage(chunk + 1, (chunk + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- Z -> LDS (accumulator layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*kh), then the 9-term stencil ----
+#pragma unroll
+  for (int t = 0; t < TMW; ++t) {
+    if (wave + NW * t >= CO_MT) continue;
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wave + NW * t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        Zs[row * ZLD + n * 32 + (lane & 31)] = acc[t][n][r];
+      }
+  }
+  __syncthreads();
+  const int Cout = p.Cout;
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+  for (int o = tid; o < CO_PH * CO_PW * Cout; o += NT) {
+    const int pix = o / Cout, co = o - pix * Cout;
+    const int py = pix / CO_PW, px = pix - py * CO_PW;
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy >= p.Hout || ox >= p.Wout) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      s += Zs[((py + ky) * CO_TW + px + kx) * ZLD + tap * Cout + co];
+    }
+    outz[((long long)oy * p.Wout + ox) * p.ldo + co] = s * p.alpha + (p.bias ? p.bias[co] : 0.f);
+  }
+}
+
+size_t conv_out_smem(int Cin, int TN) {
+  const size_t w = (size_t)(Cin / 16) * 4 * 32 * TN * 16, a = 2 * (size_t)CO_NPIX * 64;
+  const size_t z = (size_t)CO_MT * 32 * (32 * TN + 1) * sizeof(float);
+  return (w + a > z) ? w + a : z;
+}
+
+bool conv_out_supported(const GemmArgs& a) {
+  return a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats &&
+         a.Cout * 9 <= 32 /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile: 581 vs 587 us */ && (a.Cin & 15) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
+}
+
+hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
+  if (!conv_out_supported(a)) return hipErrorInvalidValue;
+  const size_t smem = conv_out_smem(a.Cin, 1);
+  dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(conv_out_kernel<1>, grid, block, smem, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace asyrp

@@ -630,6 +630,21 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
         return 0;
       }
     }
+    // the UNet's last conv: taps folded into N (conv_out.hip) when its image exists and the launch has that shape
+    {
+      auto cit = c.e->xw.find(wname + "#co");
+      if (cit != c.e->xw.end() && !sc0 && !want_stats) {
+        GemmArgs t = g;
+        t.wpk = cit->second.p;
+        t.cout_pad = cit->second.cout_pad;
+        t.alpha = 1.0f / (cit->second.wscale * f16x3_act_scale());
+        if (conv_out_supported(t)) {
+          double fl = 0, by = 0;
+          if (c.e->prof_on) gemm_work(g, &fl, &by);
+          return run_timed(c, 300000 + Cout, fl, by, [&]() { return launch_conv_out(t, c.s); });
+        }
+      }
+    }
     // 8x8 layers: M x N has fewer tiles than the chip has CUs and K is thousands deep -> split K over 8 workgroups per
     // tile and reduce in a second, tiny launch.  The decision depends on the layer shape only (never on the batch), so
     // an image's result does not depend on what it is batched with.
@@ -1670,6 +1685,15 @@ int asyrp_finalize_params(asyrp_engine* e) {
         if (isd(s.key)) {
           TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
           if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+          // the UNet's last conv (conv_out / out.2): a second image with the 9 taps folded into N for conv_out.hip
+          if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= 32 &&
+              cin % 16 == 0 && cin <= 256) {
+            std::vector<float> w1((size_t)9 * cout * cin);
+            for (int co = 0; co < cout; ++co)
+              for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t) w1[((size_t)(t * cout + co)) * cin + ci] = v[((size_t)co * cin + ci) * 9 + t];
+            TRY(pack_x3(e, s.key + "#co", w1, 9 * cout, cin, 1));
+          }
         }
         // a ResnetBlock / ResBlock with a 1x1 shortcut: fused image (second conv ++ shortcut) and fused bias
         const char* c2 = (e->cfg.family == ASYRP_FAMILY_IDDPM) ? ".out_layers.3" : ".conv2";
@@ -2290,6 +2314,31 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
     g.wpk = xp;
     g.cout_pad = ((Cout + 127) / 128) * 128;
     g.alpha = 1.0f / (wscale * f16x3_act_scale());
+    if (tile == 13) {   // the taps-in-N kernel of the UNet's last conv (conv_out.hip): its own weight image
+      std::vector<float> w1((size_t)9 * Cout * Cin);
+      for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+          for (int t = 0; t < 9; ++t) w1[((size_t)(t * Cout + co)) * Cin + ci] = hw[((size_t)co * Cin + ci) * 9 + t];
+      float *w1d, *xp1;
+      TRY(dalloc(w1.size(), &w1d));
+      HIPCHK(hipMemcpy(w1d, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY(dalloc((f16x3_packed_halfs(9 * Cout, Cin, 1) + 1) / 2, &xp1));
+      HIPCHK(launch_pack_f16x3(w1d, xp1, 9 * Cout, Cin, 1, wscale, s));
+      g.wpk = xp1;
+      g.cout_pad = ((9 * Cout + 127) / 128) * 128;
+      g.tile = 0;
+      if (ksize != 3 || !conv_out_supported(g)) {
+        for (void* p : tmp) (void)hipFree(p);
+        return fail(ASYRP_EINVAL, "shape not covered by the conv_out kernel");
+      }
+      hipError_t le = launch_conv_out(g, s);
+      if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);
+      hipError_t se = hipStreamSynchronize(s);
+      for (void* p : tmp) (void)hipFree(p);
+      if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_out launch: ") + hipGetErrorString(le));
+      if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_out sync: ") + hipGetErrorString(se));
+      return 0;
+    }
   }
   hipError_t le = launch_gemm(g, s);
   if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);

@@ -70,6 +70,11 @@ float f16x3_act_scale();
 // algorithmic work of one launch (2*M*N*K flops; A read once + out written once + weights once)
 void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 
+// conv_out.hip: the UNet's last 3x3 convolution (Cout = 3 / 6) with the taps folded into N; `a.wpk` = f16x3 image of the equivalent
+// 1x1 conv w1[tap*Cout + co][ci] (launch_pack_f16x3 with cout = 9*Cout, ks = 1), prologue scale/shift + SiLU mandatory
+bool conv_out_supported(const GemmArgs& a);
+hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s);
+
 // GroupNorm(32) statistics of an NHWC tensor (two concatenated sources allowed) -> per-(image,channel)
 // scale/shift so that y = x*scale + shift == GN(x)*gamma+beta; optional FiLM (scale,shift) folding:
 // y = GN(x)*(1+fs)+fsh.  `partial` is scratch of gn_partial_floats() floats (holds doubles).

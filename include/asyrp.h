@@ -217,7 +217,8 @@ int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms
  *   upsample: nearest x2 before the conv (:84-85).
  *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0).
  *   conv_math: enum asyrp_conv_math; tile: 0 = the launcher's own choice, else force one tile shape of that
- *   kernel family (1..5) so every compiled variant can be parity-tested. */
+ *   kernel family so every compiled variant can be parity-tested; tile 13 = the taps-in-N kernel of the UNet's last
+ *   convolution (csrc/conv_out.hip: 3x3, stride 1, Cout*9 <= 32, GroupNorm + SiLU prologue required). */
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                     const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
                     const float* gn_weight, const float* gn_bias, float gn_eps, int silu, const float* chan_add,

@@ -88,6 +88,19 @@ def test_f16x3_narrow_tile_for_conv_out():
         assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out tile {tile} Cout {Cout}", **TIGHT)
 
 
+@pytest.mark.parametrize("Cout,Cin,H,W", [(3, 128, 32, 32), (2, 64, 32, 32), (3, 32, 40, 24), (1, 256, 16, 48), (3, 128, 256, 256)])
+def test_conv_out_taps_in_n_kernel(Cout, Cin, H, W):
+    """csrc/conv_out.hip (tile 13): the UNet's last conv with the 9 taps folded into N, GroupNorm + SiLU prologue; partial tiles
+    (40x24), ragged output widths, and the production size (the 6-channel iDDPM head stays on the implicit-GEMM tile)."""
+    B = 2 if H < 256 else 1
+    x = hash_normal(f"co.x.{Cout}.{Cin}.{H}.{W}", (B, Cin, H, W))
+    w = hash_uniform(f"co.w.{Cout}.{Cin}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"co.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform("co.g", (Cin,)), 0.1 * hash_uniform("co.be", (Cin,)))
+    got = hip_conv(x, w, b, gn=gn, silu=True, tile=13)
+    assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out kernel Cout={Cout} Cin={Cin} {H}x{W}", **TIGHT)
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
