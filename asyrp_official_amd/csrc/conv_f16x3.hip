@@ -718,6 +718,278 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The 256 x 128 tile of the big 3x3 layers on v_mfma_f32_16x16x32_f16 ("K32").
+// The chip is power-limited under the f16 matrix instructions on non-zero data, so the sustained rate of an instruction stream
+// is set by the ENERGY an instruction costs, not by its issue rate: scripts/calib/mfma_energy.hip measures 1.62 PFLOP/s for
+// v_mfma_f32_32x32x16_f16 against 1.89 PFLOP/s for v_mfma_f32_16x16x32_f16 on the same UNet-like operands (the 16x16x32 form
+// reduces 32 products into each accumulator element, i.e. moves half the fp32 accumulator bytes per flop), and
+// scripts/calib/loop_shapes.hip 482 -> 546 TFLOP/s-equivalent for this tile's loop shape (profiles/r02s_*).
+// Same workgroup shape, LDS images, weight image, staging and epilogue semantics as igemm_f16x3_kernel<XCfg<4,2,2,2,3,1>>; what
+// changes is the K-step: ONE instruction reduces K = 32 = two consecutive (chunk, tap) slices of the flat K sequence
+// (chunk-major, 9 taps per 16-channel chunk).  Lane l of a wave feeds row l & 15 and the 8-element k group l >> 4; groups
+// 0,1 are the two channel halves of the step's first tap, groups 2,3 those of its second tap -- every lane computes its own
+// LDS address, so the tap (and, across a chunk boundary, the halo buffer) is just a per-lane offset.  Cin % 32 == 0 makes the
+// number of slices even.  A wave owns 64 pixels (4 tile rows of 16) x 64 channels = 4 x 4 accumulator blocks of 16 x 16
+// (64 VGPRs): per step 16 ds_read_b128 feed 48 instructions.  The unit planes of the halo tile are pitched at 336 pixels
+// (21 x 256 B) so that the two channel-half planes a ds_read_b128 lane group touches are bank-congruent.
+// Summation order inside a K = 32 instruction differs from two K = 16 ones: results equal the other tiles' to fp32 rounding
+// (tested at 1e-6 relative), not bitwise; the tile choice depends on the layer shape only, so batch invariance holds.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct K32Cfg {
+  static constexpr int NW = 8, NT = 512, BM = 256, BN = 128, PW = 16, PH = 16, TW = 18, TH = 18;
+  static constexpr int NPIX = TH * TW;                         // 324 halo pixels
+  static constexpr int PLANE = 336;                            // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
+  static constexpr int A_BYTES = 4 * PLANE * 16;               // [4 units][PLANE][16 B]
+  static constexpr int B_BYTES = BN * 64;                      // one (chunk, tap) weight slice [4 units][BN][16 B]
+  static constexpr int SLOT_BYTES = 2 * B_BYTES;               // the two slices of a K = 32 step
+  static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
+  static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;   // 74 KB: two workgroups per CU
+};
+
+__global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const GemmArgs p) {
+  using T = K32Cfg;
+  constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE;
+  constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB)
+  char* const As = smem + 2 * SLOT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int zo = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+  int bx = blockIdx.x;
+  if (p.xmap) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);   // XCD-aware block -> tile map (see igemm_f16x3_kernel)
+  const int tiles_x = (p.Wout + PW - 1) / PW;
+  const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+  const int oy0 = ty * T::PH, ox0 = tx * PW;
+  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
+  const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo : nullptr;
+  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
+  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
+  const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
+  const int Cout = p.Cout, c0s = p.c0;
+  const int nch = p.Cin / XKC;               // even (launcher: Cin % 32 == 0)
+
+  // ---- A staging map: work item = (halo pixel, 8-channel half), as in igemm_f16x3_kernel ----
+  const int hf = tid & 1;
+  int aoff[NA];   // source pixel index, -1 = zero padding, -2 = no work item
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tid + i * NT;
+    const int pix = u >> 1;
+    int off = -2;
+    if (u < NU) {
+      const int iy = pix / TW, ix = pix - iy * TW;
+      const int gy = oy0 - p.pad + iy, gx = ox0 - p.pad + ix;
+      const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
+      off = (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
+    }
+    aoff[i] = off;
+  }
+  float4 areg[NA][2];
+  auto gload_A = [&](int chunk) {
+    const int c = chunk * XKC + hf * 8;
+    const bool second = (chunk * XKC >= c0s);                 // a chunk lies in one source (c0 % 16 == 0)
+    const float* __restrict__ base = second ? a1 + (c - c0s) : a0 + c;
+    const int ld = second ? p.lda1 : p.lda0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      const int sp = aoff[i];
+      if (sp >= 0) {
+        const float* src = base + (long long)sp * ld;
+        v0 = *reinterpret_cast<const float4*>(src);
+        v1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      areg[i][0] = v0;
+      areg[i][1] = v1;
+    }
+  };
+  auto write_A = [&](int chunk, int buf) {
+    const int c = chunk * XKC + hf * 8;
+    float4 sreg[4];
+    if (ps) {
+      sreg[0] = *reinterpret_cast<const float4*>(ps + c);
+      sreg[1] = *reinterpret_cast<const float4*>(ps + c + 4);
+      sreg[2] = *reinterpret_cast<const float4*>(psh + c);
+      sreg[3] = *reinterpret_cast<const float4*>(psh + c + 4);
+    }
+    const float sc[8] = {sreg[0].x, sreg[0].y, sreg[0].z, sreg[0].w, sreg[1].x, sreg[1].y, sreg[1].z, sreg[1].w};
+    const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (aoff[i] == -2) continue;
+      float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
+                    areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      if (aoff[i] >= 0) {
+        if (ps) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = __builtin_fmaf(t[j], sc[j], sh[j]);
+        }
+        if (p.silu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = silu_fast(t[j]);
+        }
+      }
+      h8 hi, lo;
+      split8(t, hi, lo);
+      const int pix = (tid + i * NT) >> 1;
+      char* dst = As + buf * A_BYTES + (hf * PLANE + pix) * 16;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + 2 * PLANE * 16) = lo;
+    }
+  };
+  // the two weight slices of K-step s are consecutive in the packed image: 16 1-KiB LDS-DMA pieces, two per wave
+  auto issue_slot = [&](int s, int slot) {
+    const int u = wave >> 1, part = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* src = wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
+      char* dst = Bs + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
+  const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
+  const int a_lane = (kh * PLANE + (wm * 4) * TW + r16) * 16;            // + tm * TW * 16 (+ 2 * PLANE * 16 for x_lo) + tap offset
+  const int b_lane = tp * B_BYTES + (kh * BN + wn * 64 + r16) * 16;       // + tn * 256 (+ 2 * BN * 16 for w_lo) + slot
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
+
+  issue_slot(0, 0);
+  gload_A(0);
+  write_A(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nsteps = nch * 9 / 2;
+  int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) issue_slot(s + 1, (s + 1) & 1);
+    int c1 = c0, t1 = t0 + 1;
+    if (t1 == 9) { t1 = 0; ++c1; }
+    const int ky0 = (t0 * 11) >> 5, ky1 = (t1 * 11) >> 5;     // t / 3 for t in 0..8
+    const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - 3 * ky0)) * 16;
+    const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - 3 * ky1)) * 16;
+    const char* A = As + a_lane + (tp ? offA1 : offA0);
+    const char* B = Bs + (s & 1) * SLOT_BYTES + b_lane;
+    // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile
+    h8 fa[4], fb[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * TW * 16 + 2 * PLANE * 16);   // x_lo
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256);                         // w_hi
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * TW * 16);                    // x_hi
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + 2 * BN * 16);           // w_lo
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+    // two slices on
+    t0 += 2;
+    if (t0 >= 9) { t0 -= 9; ++c0; }
+    // the halo tile of the chunk the NEXT step's second slice belongs to must be in LDS before the barrier below; its
+    // buffer held chunk need-2, last read at least one barrier ago
+    const int need = (t0 == 8) ? c0 + 1 : c0;
+    if (need > staged && need < nch) {
+      gload_A(need);
+      write_A(need, need & 1);
+      staged = need;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r ----
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+  const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
+  const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
+  const bool has_b = (p.bias != nullptr), has_c = (cadd != nullptr);
+  const bool full = (n0 + BN <= Cout) && (oy0 + T::PH <= p.Hout) && (ox0 + PW <= p.Wout);
+  double* const red = reinterpret_cast<double*>(smem);   // [4 wave rows][BN][2]; LDS is free after the last barrier
+  const bool want_stats = (p.stats != nullptr);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = n0 + wn * 64 + tn * 16 + r16;
+    const bool nok = full || (n < Cout);
+    const float add = nok ? ((has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f)) : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int oy = oy0 + wm * 4 + tm;
+      int pixel[4];
+      bool ok[4];
+      float rv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = ox0 + 4 * g + r;
+        ok[r] = nok && (full || (oy < p.Hout && ox < p.Wout));
+        pixel[r] = oy * p.Wout + ox;
+        rv[r] = 0.f;
+        if (rz && ok[r]) rv[r] = p.rups ? rz[((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) * p.ldr + n] : rz[pixel[r] * p.ldr + n];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (ok[r]) {
+          const float v = (acc[tm][tn][r] * p.alpha + add) + rv[r];
+          outz[pixel[r] * p.ldo + n] = v;
+          if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+        }
+      }
+    }
+    if (want_stats) {   // fixed-order reduction over the four row groups of the block, then over the wave rows below
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (g == 0) {
+        double* d = red + ((size_t)wm * BN + wn * 64 + tn * 16 + r16) * 2;
+        d[0] = s1;
+        d[1] = s2;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      if (n0 + c < Cout) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += red[((size_t)w * BN + c) * 2];
+          s2 += red[((size_t)w * BN + c) * 2 + 1];
+        }
+        double* dst = p.stats + (((size_t)zo * gridDim.x + bx) * Cout + n0 + c) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
 static bool is_vec(const GemmArgs& a) {
   return (((a.c0 | a.c1 | a.lda0 | a.lda1 | a.Cin) & 15) == 0) && ((((uintptr_t)a.a0) | ((uintptr_t)a.a1)) & 15) == 0 &&
          (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
@@ -761,6 +1033,36 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
+}
+
+static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
+  using T = K32Cfg;
+  const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
+  const int gy = (a.Cout + T::BN - 1) / T::BN;
+  dim3 grid(gx, gy, a.Z), block(T::NT);
+  GemmArgs ax = a;
+  ax.xmap = (xcd_map_enabled() && gx >= 16 && (gx & 7) == 0 && (gy * (long long)gx) % 8 == 0) ? 1 : 0;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(igemm_f16x3_k32_kernel, grid, block, T::SMEM, s, ax);
+  return hipGetLastError();
+}
+
+// the layers the K32 kernel takes over from the 8-wave 32x32x16 tile (everything else about the tile is the same)
+static bool k32_ok(const GemmArgs& a) {
+  return a.ks == 3 && a.stride == 1 && !a.s0 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
+}
+// A/B switch: ASYRP_MAIN_TILE=6 keeps the 32x32x16 organisation for the automatic choice
+static bool k32_preferred() {
+  static const bool on = [] { const char* e = getenv("ASYRP_MAIN_TILE"); return !(e && e[0] == '6'); }();
+  return on;
 }
 
 // the 256x128 tile the big 3x3 layers run on: 8 waves (4 per SIMD with two workgroups per CU), plain per-tap loop.
@@ -807,9 +1109,11 @@ static int requested_tile_x(const GemmArgs& a) {
 // the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
 static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
-  const int t = requested_tile_x(a);
+  int t = requested_tile_x(a);
+  if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
+  if (t == XT_256x128W8 && !a.tile && k32_ok(a) && k32_preferred()) t = XT_256x128K32;
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x32) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -825,7 +1129,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x32:
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32:
       bm = 256; break;
     case XT_128x128: bm = 128; break;
     default: bm = 64;
@@ -887,6 +1191,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
+      case XT_256x128K32: return launch_k32(a, s);
     }
   } else {
     switch (tile) {

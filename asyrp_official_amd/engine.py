@@ -271,6 +271,8 @@ class Engine:
         if fam == 1:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
                     12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
+            if tid == 7:
+                return "f16x3", "asyrp::igemm_f16x3_k32_kernel"
             return "f16x3", "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
         tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
         return "f32", "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))

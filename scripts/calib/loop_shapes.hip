@@ -117,6 +117,94 @@ static void run(const char* name, int wgs_per_cu) {
   (void)hipFree(out);
 }
 
+
+// the same wave tile (64 x 64 outputs) on v_mfma_f32_16x16x32_f16: one step = K 32 (two taps of a 16-channel chunk), 4 x 4
+// accumulator blocks of 16 x 16, (4 + 4) * 2 fragments of 1 KB (the same LDS bytes per flop as the 32x32x16 organisation)
+// and 48 instructions of 16 cycles.  HALF: B fragments of all four column blocks stay live, the A fragments are fetched for
+// two row blocks at a time (24 fragment registers instead of 32).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NW, bool BAR, int MINW, bool HALF>
+__global__ void __launch_bounds__(NW * 64, MINW) loop16_kernel(float* out, int steps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LDS_BYTES = 32 * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < LDS_BYTES / 2; i += NW * 64) {
+    const unsigned h = hashu(i * 2654435761u + blockIdx.x);
+    reinterpret_cast<_Float16*>(smem)[i] = (_Float16)(((int)(h & 2047) - 1024) * (1.0f / 1024.0f));
+  }
+  __syncthreads();
+  f32x4 acc[4][4];
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b)
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+  const int wave = tid >> 6;
+  auto frag = [&](int off) { return *reinterpret_cast<const h8*>(smem + (off & (LDS_BYTES - 1)) + lane * 16); };
+  for (int s = 0; s < steps; ++s) {
+    const int base = ((s * 7 + wave * 3) & 15) * 1024;
+    h8 fb[4];
+    // pass 1: x_lo * w_hi, pass 2: x_hi * w_hi (same B), pass 3: x_hi * w_lo (new B)
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      if (pass != 1) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b] = frag(base + 16384 + b * 2048 + (pass == 2 ? 1024 : 0));
+      }
+      if (HALF) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          h8 fa[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) fa[a] = frag(base + (hh * 2 + a) * 2048 + (pass == 0 ? 0 : 1024));
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              acc[hh * 2 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[hh * 2 + a][b], 0, 0, 0);
+        }
+      } else {
+        h8 fa[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = frag(base + a * 2048 + (pass == 0 ? 0 : 1024));
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (BAR) __builtin_amdgcn_s_barrier();
+  }
+  float sum = 0.f;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b)
+      for (int r = 0; r < 4; ++r) sum += acc[a][b][r];
+  out[blockIdx.x * (NW * 64) + tid] = sum;
+}
+
+template <int NW, bool BAR, int MINW, bool HALF>
+static void run16(const char* name, int wgs_per_cu) {
+  const int steps = 2000, grid = 256 * wgs_per_cu;
+  float* out;
+  (void)hipMalloc(&out, (size_t)grid * NW * 64 * sizeof(float));
+  auto k = loop16_kernel<NW, BAR, MINW, HALF>;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), 32 * 1024, 0, out, steps);
+  (void)hipDeviceSynchronize();
+  double mean = 0.0;
+  const int reps = 5;
+  for (int rep = 0; rep < reps; ++rep) {
+    (void)hipEventRecord(e0, 0);
+    for (int j = 0; j < 3; ++j) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), 32 * 1024, 0, out, steps);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    mean += 3.0 * (double)grid * NW * steps * 48 * 16384.0 / (ms * 1e-3) / 1e12 / reps;
+  }
+  printf("%-72s %7.1f TFLOP/s f16 MFMA = %6.1f fp32-equivalent; 0.33 ds_read_b128 per (half-size) MFMA\n", name, mean, mean / 3.0);
+  (void)hipFree(out);
+}
+
 int main() {
   run<8, 2, 2, false, 4>("8 waves x (64x64), 2 WG/CU = 4 waves/SIMD, no barrier", 2);
   run<8, 2, 2, true, 4>("8 waves x (64x64), 2 WG/CU = 4 waves/SIMD, barrier per tap   [main tile]", 2);
@@ -127,5 +215,10 @@ int main() {
   run<4, 4, 4, true, 1>("4 waves x (128x128), 1 WG/CU = 1 wave/SIMD, barrier per tap", 1);
   run<8, 4, 2, true, 2>("8 waves x (128x64), 1 WG/CU = 2 waves/SIMD, barrier per tap", 1);
   run<16, 2, 2, true, 4>("16 waves x (64x64), 1 WG/CU = 4 waves/SIMD, barrier per tap", 1);
+  run16<8, true, 4, false>("16x16x32: 8 waves x (64x64), 2 WG/CU, barrier per K=32 step, 4+4 fragments per pass", 2);
+  run16<8, true, 4, true>("16x16x32: 8 waves x (64x64), 2 WG/CU, barrier per K=32 step, 2+4 fragments per half pass", 2);
+  run16<8, false, 4, true>("16x16x32: 8 waves x (64x64), 2 WG/CU, no barrier, 2+4 fragments per half pass", 2);
+  run<8, 2, 2, true, 4, true>("32x32x16 again: 8 waves x (64x64), 2 WG/CU, barrier per tap, fragments PER PASS", 2);
+  run16<8, true, 4, true>("16x16x32 again: 8 waves x (64x64), 2 WG/CU, barrier per step, half passes", 2);
   return 0;
 }

@@ -29,6 +29,20 @@ if __name__ == "__main__":
             ms, tf = run(256, 128, 0, 128, 3, tile=tile, iters=5)
             print(f"tile {tile} 128->128 @256 B={B}: {ms:.3f} ms {tf:.1f} TFLOP/s")
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
+        tiles = (6, 7)
+        print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")
+        for (H, Ch, C1, Co, kw) in ((256, 128, 0, 128, {}), (256, 128, 0, 128, dict(res=1)), (256, 128, 128, 128, {}),
+                                    (128, 128, 0, 128, {}), (128, 128, 128, 128, {}), (64, 256, 0, 256, {}),
+                                    (64, 256, 256, 256, {}), (128, 128, 0, 128, dict(ups=1, pro=0)), (32, 256, 0, 256, {})):
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    r[t].append(run(H, Ch, C1, Co, 3, tile=t, iters=6, **kw)[1])
+            med = {t: sorted(r[t])[2] for t in tiles}
+            print(f"  {Ch}+{C1}->{Co} @{H} {kw}: " + "  ".join(f"t{t} {med[t]:5.1f} ({med[t] / med[6]:.3f})" for t in tiles),
+                  flush=True)
+        sys.exit(0)
     print(f"B={B}")
     layers = [("down.0 conv 128->128 @256", 256, 128, 0, 128, 3, {}),
               ("up.0 conv1 256->128 @256 (concat)", 256, 128, 128, 128, 3, {}),

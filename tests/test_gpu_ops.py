@@ -101,14 +101,14 @@ def test_conv_out_taps_in_n_kernel(Cout, Cin, H, W):
     assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out kernel Cout={Cout} Cin={Cin} {H}x{W}", **TIGHT)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
     """Force each compiled tile shape of the f16x3 family (256x128 4-wave, 128x128, 64x128, 64x64, 256x64, 256x128
-    8-wave) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32 concatenated channels, 160 output
-    channels (partial N tile)."""
-    if tile == 6 and k == 1:
-        pytest.skip("the 8-wave tile is compiled for 3x3 convolutions only")
+    8-wave, 256x128 8-wave on the 16x16x32 instruction) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32
+    concatenated channels, 160 output channels (partial N tile)."""
+    if tile in (6, 7) and k == 1:
+        pytest.skip("the 8-wave tiles are compiled for 3x3 convolutions only")
     B, H, W = 2, 40, 24
     x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
     x1 = hash_normal(f"tile.x1.{k}", (B, 32, H, W)) * 3.0
@@ -137,7 +137,8 @@ def test_f16x3_every_tile_shape(tile, k):
 
 
 @pytest.mark.parametrize("tile,k,H,W,Cout,offset", [(0, 3, 16, 16, 64, 0.0), (1, 3, 40, 24, 160, 0.0), (2, 1, 40, 24, 96, 0.0),
-                                                    (3, 3, 20, 12, 96, 30.0), (4, 3, 8, 8, 32, 0.0), (6, 3, 32, 32, 128, 5.0)])
+                                                    (3, 3, 20, 12, 96, 30.0), (4, 3, 8, 8, 32, 0.0), (6, 3, 32, 32, 128, 5.0),
+                                                    (7, 3, 32, 32, 128, 5.0), (7, 3, 40, 24, 160, 0.0)])
 def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     """The conv epilogue's per-block {sum, sumsq} partials + finalize == GroupNorm of the conv output (incl. partial
     tiles, 3-channel groups that are not lane-aligned, and a large mean offset that would break a naive fp32 E[x^2]-m^2)."""
@@ -160,6 +161,47 @@ def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
     want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,C0,H,W,Cout,ups", [(32, 32, 16, 16, 128, 0), (64, 32, 48, 32, 128, 0), (160, 96, 20, 36, 192, 0),
+                                                 (128, 128, 16, 16, 128, 1), (256, 128, 64, 64, 128, 0)])
+def test_f16x3_k32_tile_matches_the_32x32x16_tile(Cin, C0, H, W, Cout, ups):
+    """The 8-wave tile on v_mfma_f32_16x16x32_f16 (tile 7: one instruction spans two consecutive (chunk, tap) slices) against the
+    fp32 reference AND against the 32x32x16 organisation of the same tile (tile 6), whose products are the same and whose
+    summation order differs only inside a K = 32 block: odd and even chunk counts per source, a step that straddles the chunk
+    boundary (and the two concatenated sources), partial tiles, the fused nearest-x2 upsample, GroupNorm + SiLU prologue."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    B, C1 = 2, Cin - C0
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    tag = f"k32.{Cin}.{C0}.{H}.{Cout}"
+    x0 = hash_normal(tag + ".x0", (B, C0, Hs, Ws))
+    x1 = hash_normal(tag + ".x1", (B, C1, Hs, Ws)) * 2.0 if C1 else None
+    w = hash_uniform(tag + ".w", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(tag + ".b", (Cout,))
+    res = hash_normal(tag + ".r", (B, Cout, H, W))
+    ca = hash_normal(tag + ".ca", (B, Cout))
+    gn = (1 + 0.1 * hash_uniform(tag + ".g", (Cin,)), 0.1 * hash_uniform(tag + ".be", (Cin,)))
+    d = lambda t: None if t is None else t.cuda().contiguous()
+
+    def run(tile):
+        y = torch.empty((B, Cout, H, W), device="cuda")
+        a0, a1, wd, bd, g0, g1, cad, rd = map(d, (x0, x1, w, b, gn[0], gn[1], ca, res))
+        _lib.check(lib.asyrp_op_conv2d(0, _p(a0), C0, _p(a1), C1, B, Hs, Ws, _p(wd), _p(bd), Cout, 3, 1, ups, _p(g0), _p(g1),
+                                       1e-6, 1, _p(cad), _p(rd), _p(y), _lib.MATH_F16X3, tile, None))
+        torch.cuda.synchronize()
+        return y.cpu()
+
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    x = F.group_norm(x, 32, gn[0], gn[1], eps=1e-6)
+    x = x * torch.sigmoid(x)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    want = res + F.conv2d(x, w, b, padding=1) + ca[:, :, None, None]
+    got7, got6 = run(7), run(6)
+    assert_close(got7, want, what=f"tile 7 {tag}", **TIGHT)
+    assert_close(got7, got6, what=f"tile 7 vs tile 6 {tag}", rtol=1e-5, atol=2e-6)
+    assert torch.equal(got7, run(7)), "the K32 tile must be deterministic"
 
 
 @pytest.mark.parametrize("B,Ch,C0,C1,Cout,H,W", [(1, 64, 64, 32, 64, 16, 16), (2, 128, 128, 128, 128, 40, 24),
