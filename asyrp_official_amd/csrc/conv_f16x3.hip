@@ -750,6 +750,12 @@ struct K32Cfg {
   static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;   // 74 KB: two workgroups per CU
 };
 
+// SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
+//     tensor (s0|s1) (weights appended to the image, as for igemm_f16x3_kernel); two of them make a K = 32 step.  Such a step
+//     needs BOTH its 16-channel chunks in LDS at once, so the shortcut phase turns the two halo buffers into ONE centre-only tile
+//     of 32 channels ([8 units][256 pixels][16 B] = 32 KB): raw loads for the next step travel in registers under the matrix
+//     passes, the split + LDS write sits between two barriers (Cin2 % 32 == 0).
+template <bool SC>
 __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const GemmArgs p) {
   using T = K32Cfg;
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE;
@@ -876,21 +882,12 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int nsteps = nch * 9 / 2;
-  int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) issue_slot(s + 1, (s + 1) & 1);
-    int c1 = c0, t1 = t0 + 1;
-    if (t1 == 9) { t1 = 0; ++c1; }
-    const int ky0 = (t0 * 11) >> 5, ky1 = (t1 * 11) >> 5;     // t / 3 for t in 0..8
-    const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - 3 * ky0)) * 16;
-    const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - 3 * ky1)) * 16;
-    const char* A = As + a_lane + (tp ? offA1 : offA0);
-    const char* B = Bs + (s & 1) * SLOT_BYTES + b_lane;
-    // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile
+  // one K = 32 step: 16 fragments, 48 matrix instructions; pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
+  // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
+  auto mma_step = [&](const char* A, const int a_tm, const int a_lo, const char* B) {
     h8 fa[4], fb[4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * TW * 16 + 2 * PLANE * 16);   // x_lo
+    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm + a_lo);                // x_lo
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256);                         // w_hi
 #pragma unroll
@@ -898,7 +895,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * TW * 16);                    // x_hi
+    for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm);                       // x_hi
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -909,6 +906,58 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+  };
+
+  // ---- shortcut phase staging: work item = (centre pixel, 8-channel quarter q of the step's 32 raw channels) ----
+  const int q = tid & 3;
+  int scoff[2] = {-1, -1};
+  auto sc_load = [&](int j) {
+    const int chunk = 2 * j + (q >> 1);
+    const bool second = (chunk * XKC >= p.sc0);
+    const int cc = chunk * XKC + (q & 1) * 8;
+    const float* __restrict__ base = second ? p.s1 + (long long)zo * p.s1_zo + (cc - p.sc0) : p.s0 + (long long)zo * p.s0_zo + cc;
+    const int ld = second ? p.lds1 : p.lds0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      const int sp = scoff[i];
+      if (sp >= 0) {
+        const float* src = base + (long long)sp * ld;
+        v0 = *reinterpret_cast<const float4*>(src);
+        v1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      areg[i][0] = v0;
+      areg[i][1] = v1;
+    }
+  };
+  auto sc_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
+                          areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      h8 hi, lo;
+      split8(t, hi, lo);
+      const int pix = (tid + i * NT) >> 2;
+      char* dst = As + (q * 256 + pix) * 16;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + 4 * 256 * 16) = lo;
+    }
+  };
+
+  const int nsteps3 = nch * 9 / 2;
+  const int nsc = SC ? p.Cin2 / (2 * XKC) : 0;
+  const int nsteps = nsteps3 + nsc;
+  int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
+  for (int s = 0; s < nsteps3; ++s) {
+    if (s + 1 < nsteps) issue_slot(s + 1, (s + 1) & 1);
+    int c1 = c0, t1 = t0 + 1;
+    if (t1 == 9) { t1 = 0; ++c1; }
+    const int ky0 = (t0 * 11) >> 5, ky1 = (t1 * 11) >> 5;     // t / 3 for t in 0..8
+    const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - 3 * ky0)) * 16;
+    const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - 3 * ky1)) * 16;
+    const char* A = As + a_lane + (tp ? offA1 : offA0);
+    const char* B = Bs + (s & 1) * SLOT_BYTES + b_lane;
+    mma_step(A + 0, TW * 16, 2 * PLANE * 16, B);
     // two slices on
     t0 += 2;
     if (t0 >= 9) { t0 -= 9; ++c0; }
@@ -922,6 +971,28 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (SC) {
+    const char* const Asc = As + (kq * 256 + wm * 64 + r16) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pix = (tid + i * NT) >> 2;
+      const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+      scoff[i] = (gy < p.Hout && gx < p.Wout) ? gy * p.Wout + gx : -1;
+    }
+    sc_load(0);   // (the only exposed load of the phase: issuing it under the last 3x3 step costs the main loop 16 live registers)
+    for (int j = 0; j < nsc; ++j) {
+      const int s = nsteps3 + j;
+      sc_write();                                           // loads landed before the previous step's closing barrier
+      if (s + 1 < nsteps) issue_slot(s + 1, (s + 1) & 1);
+      if (j + 1 < nsc) sc_load(j + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is written; the loads above stay in flight
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      mma_step(Asc, 256, 4 * 256 * 16, Bs + (s & 1) * SLOT_BYTES + b_lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r ----
@@ -1035,6 +1106,7 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <bool SC>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   using T = K32Cfg;
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
@@ -1046,18 +1118,19 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<SC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(igemm_f16x3_k32_kernel, grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL(igemm_f16x3_k32_kernel<SC>, grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
 // the layers the K32 kernel takes over from the 8-wave 32x32x16 tile (everything else about the tile is the same)
 static bool k32_ok(const GemmArgs& a) {
-  return a.ks == 3 && a.stride == 1 && !a.s0 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
+  if (a.s0 && (a.ups || (a.Cin2 & 31) || a.Cin2 < 32)) return false;   // fused shortcut: an even number of raw slices
+  return a.ks == 3 && a.stride == 1 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
 }
 // A/B switch: ASYRP_MAIN_TILE=6 keeps the 32x32x16 organisation for the automatic choice
 static bool k32_preferred() {
@@ -1123,7 +1196,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
@@ -1179,6 +1252,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
+    if (tile == XT_256x128K32) return launch_k32<true>(a, s);
     return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
@@ -1191,7 +1265,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128K32: return launch_k32(a, s);
+      case XT_256x128K32: return launch_k32<false>(a, s);
     }
   } else {
     switch (tile) {

@@ -205,10 +205,13 @@ def test_f16x3_k32_tile_matches_the_32x32x16_tile(Cin, C0, H, W, Cout, ups):
 
 
 @pytest.mark.parametrize("B,Ch,C0,C1,Cout,H,W", [(1, 64, 64, 32, 64, 16, 16), (2, 128, 128, 128, 128, 40, 24),
-                                                   (1, 32, 48, 0, 160, 20, 36)])
+                                                   (1, 32, 48, 0, 160, 20, 36), (2, 64, 48, 48, 192, 36, 20),
+                                                   (1, 96, 32, 0, 128, 16, 16)])
 def test_fused_shortcut_resblock_tail(B, Ch, C0, C1, Cout, H, W):
     """conv3x3(swish(GN(h))) + nin_shortcut(cat(x0, x1)) in one launch: the shortcut's 1x1 runs as extra single-tap K-chunks
-    of the 3x3 conv (partial tiles, two-source concat, Cout not a multiple of the N tile)."""
+    of the 3x3 conv (partial tiles, two-source concat, Cout not a multiple of the N tile).  Channel counts that are multiples of
+    32 run on the 16x16x32 form of the main tile (two raw slices per step; 48+48: a step straddles the two sources), the others
+    (48 raw channels; 96 = an odd number of 16-channel chunks is still a multiple of 32) on the 32x32x16 form."""
     from asyrp_official_amd import _lib
     lib = _lib.load()
     tag = f"sc.{Ch}.{C0}.{C1}.{Cout}"
