@@ -162,8 +162,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   }
   const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
   const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo : nullptr;
-  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
-  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
+  const int ldps = p.ld_ps ? p.ld_ps : p.Cin;
+  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * ldps : nullptr;
+  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * ldps : nullptr;
   const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
   const int Cin = p.Cin, Cout = p.Cout, c0 = p.c0;
   const int nch1 = (Cin + XKC - 1) / XKC;   // chunks of the conv proper (the fused shortcut's chunks follow)
@@ -776,8 +777,9 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   const int oy0 = ty * T::PH, ox0 = tx * PW;
   const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
   const float* __restrict__ a1 = p.a1 ? p.a1 + (long long)zo * p.a1_zo : nullptr;
-  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * p.Cin : nullptr;
-  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * p.Cin : nullptr;
+  const int ldps = p.ld_ps ? p.ld_ps : p.Cin;
+  const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * ldps : nullptr;
+  const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * ldps : nullptr;
   const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
   const int Cout = p.Cout, c0s = p.c0;
   const int nch = p.Cin / XKC;               // even (launcher: Cin % 32 == 0)
@@ -1063,7 +1065,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
 
 static bool is_vec(const GemmArgs& a) {
   return (((a.c0 | a.c1 | a.lda0 | a.lda1 | a.Cin) & 15) == 0) && ((((uintptr_t)a.a0) | ((uintptr_t)a.a1)) & 15) == 0 &&
-         (!a.pscale || ((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0);
+         (!a.pscale || (((((uintptr_t)a.pscale) | ((uintptr_t)a.pshift)) & 15) == 0 && (a.ld_ps & 3) == 0));
 }
 
 // A/B switch of the XCD-aware tile map (ASYRP_XCD_MAP=0 disables it)

@@ -504,6 +504,10 @@ struct Ctx {
   const float* dh_in = nullptr;   // injected delta-h tensor (NHWC) -> slerp mix instead of the DeltaBlocks
   int use_mask = 0;
   Tape* tape = nullptr;           // non-null while the training forward runs the DeltaBlock and decoder #2
+  // dual-decoder steps (DDPM family): the skip-connection half of every decoder ResnetBlock's conv1 is the same in both
+  // decoder passes (conv1_shared); decoder #1 leaves it here, decoder #2 consumes it
+  bool skip_share = false;
+  std::unordered_map<std::string, Act> skip_part;
 };
 
 float* P(Ctx& c, const std::string& name) {
@@ -731,6 +735,91 @@ int tproj_gemm(Ctx& c, const float* temb_act) {
   return run_gemm(c, g);
 }
 
+// Dual-decoder steps run the decoder twice over the SAME skip tensors (models/ddpm/diffusion.py:541-577: h + delta_h and h).
+// conv1 of a decoder ResnetBlock sees swish(GroupNorm(cat(h, skip))): a skip channel's normalised value depends on h only
+// through the statistics of its own group, so every skip channel outside the one group that may straddle the two sources is
+// identical in both passes, and so is its contribution  sum_{c in clean skip} W[:, c] * act(x[c]).  That partial is computed
+// once (a conv over the clean skip channels with the matching slice of the packed weight image and of the scale/shift rows)
+// and enters both passes' conv1 -- now over (h | straddling skip channels) only -- as the residual operand.  25-33 % of
+// conv1's products disappear from every second pass.  Same products, one more fp32 rounding where the partial joins
+// (the single-decoder steps keep the one-launch form).  ASYRP_SKIP_SHARE=0 disables it.
+struct SkipPlan { int dirty, nclean; };
+static bool skip_share_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_SKIP_SHARE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static bool skip_plan(const Act& x0, const Act& x1, SkipPlan* pl) {
+  const int Cin = x0.C + x1.C;
+  if ((Cin % 32) || (x0.C % 32)) return false;
+  const int gs = Cin / 32;                                  // channels per GroupNorm(32) group
+  int dirty = (x0.C % gs) ? (x0.C / gs + 1) * gs - x0.C : 0;   // skip channels of the group that straddles h | skip
+  dirty = (dirty + 31) / 32 * 32;                            // whole K = 32 steps
+  pl->dirty = dirty;
+  pl->nclean = x1.C - dirty;
+  return pl->nclean >= 32 && (pl->nclean % 32) == 0;
+}
+// conv1 of a decoder ResnetBlock in a dual-decoder step; *done = false (nothing launched) when the layer does not qualify
+int conv1_shared(Ctx& c, const std::string& p, const Act& x0, const Act& x1, const float* sc, const float* sh, int Cout,
+                 Act* h1, bool* done) {
+  asyrp_engine* e = c.e;
+  *done = false;
+  SkipPlan pl;
+  if (!skip_plan(x0, x1, &pl)) return 0;
+  auto it = e->xw.find(p + ".conv1.weight");
+  if (it == e->xw.end()) return 0;
+  const int Cin = x0.C + x1.C, c_clean = x0.C + pl.dirty, H = x0.H, W = x0.W;
+  GemmArgs b;
+  memset(&b, 0, sizeof b);
+  b.Hin = H; b.Win = W; b.Hout = H; b.Wout = W; b.Cout = Cout;
+  b.ks = 3; b.stride = 1; b.pad = 1; b.silu = 1; b.ld_ps = Cin;
+  b.w = P(c, p + ".conv1.weight"); b.ldb = Cout;
+  b.math = MATH_F16X3; b.cout_pad = it->second.cout_pad;
+  b.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
+  b.ldo = Cout; b.o_zo = (long long)H * W * Cout; b.ZI = 1; b.Z = c.B;
+  // this pass: (h | straddling skip channels), + bias + timestep projection + the shared partial
+  GemmArgs g = b;
+  g.a0 = x0.p; g.c0 = x0.C; g.lda0 = x0.C; g.a0_zo = x0.per_image();
+  if (pl.dirty) { g.a1 = x1.p; g.c1 = pl.dirty; g.lda1 = x1.C; g.a1_zo = x1.per_image(); }
+  g.Cin = c_clean;
+  g.pscale = sc; g.pshift = sh;
+  g.wpk = it->second.p;
+  // the shared partial: clean skip channels [dirty, x1.C) = concat channels [c_clean, Cin)
+  GemmArgs s = b;
+  s.a0 = x1.p + pl.dirty; s.c0 = pl.nclean; s.lda0 = x1.C; s.a0_zo = x1.per_image();
+  s.Cin = pl.nclean;
+  s.pscale = sc + c_clean; s.pshift = sh + c_clean;
+  s.wpk = reinterpret_cast<const char*>(it->second.p) + (size_t)(c_clean / 16) * 9 * 4 * it->second.cout_pad * 16;
+  if (splitk_factor(g) > 1 || splitk_factor(s) > 1) return 0;
+  Act part;
+  auto f = c.skip_part.find(p);
+  const bool second = (f != c.skip_part.end());
+  if (!second) {
+    TRY(new_act(c, Cout, H, W, &part));
+    s.out = part.p;
+    TRY(run_gemm(c, s));
+    c.skip_part[p] = part;
+  } else {
+    part = f->second;
+  }
+  TRY(new_act(c, Cout, H, W, h1));
+  g.bias = P(c, p + ".conv1.bias");
+  g.chan_add = c.tproj + e->tproj_off.at(p); g.ld_chan_add = e->tproj_total;
+  g.resid = part.p; g.ldr = Cout; g.r_zo = part.per_image();
+  g.out = h1->p;
+  h1->st_nblk = gemm_mblocks(g);
+  float* sp = nullptr;
+  TRY(e->pool.get((size_t)c.B * h1->st_nblk * Cout * 4, &sp));
+  h1->st = reinterpret_cast<double*>(sp);
+  g.stats = h1->st;
+  TRY(run_gemm(c, g));
+  if (second) {
+    drop(c, part);
+    c.skip_part.erase(p);
+  }
+  *done = true;
+  return 0;
+}
+
 // ResnetBlock (models/ddpm/diffusion.py:151-170) on the virtual concat (x0|x1)
 int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* out) {
   asyrp_engine* e = c.e;
@@ -739,8 +828,11 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
   float *sc1, *sh1, *sc2, *sh2, *mr1 = nullptr, *mr2 = nullptr;
   TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1, nullptr, nullptr, 0, c.tape ? &mr1 : nullptr));
   Act h1;
-  TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
-           c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
+  bool shared = false;
+  if (c.skip_share && x1 && !c.tape && e->math == MATH_F16X3) TRY(conv1_shared(c, p, x0, *x1, sc1, sh1, Cout, &h1, &shared));
+  if (!shared)
+    TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
+             c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
   e->pool.put(sc1); e->pool.put(sh1);
   TRY(gn(c, h1, nullptr, p + ".norm2", 1e-6f, &sc2, &sh2, nullptr, nullptr, 0, c.tape ? &mr2 : nullptr));
   if (c.tape) {   // (the pool defers every put while a tape is recorded: the pointers below stay valid until the backward)
@@ -1227,6 +1319,8 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   drop(c, m2);
   *middle = h;
 
+  // both decoders run (and no backward tape is being recorded): share the skip halves of the decoder conv1s between them
+  c.skip_share = (index >= 0 && apply_edit && !tape && skip_share_enabled());
   if (index >= 0 && apply_edit && c.dh_in) {   // injected delta_h tensor: :518-539
     Act h2;
     TRY(new_act(c, h.C, h.H, h.W, &h2));
@@ -1254,6 +1348,9 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     drop(c, h2);
   }
   TRY(decoder(c, h, skips, et));
+  c.skip_share = false;
+  for (auto& kv : c.skip_part) drop(c, kv.second);   // (empty unless a pass stopped early)
+  c.skip_part.clear();
   for (auto& a : skips) drop(c, a);
   e->pool.put(c.tproj);
   c.tproj = nullptr;

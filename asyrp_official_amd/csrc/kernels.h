@@ -18,6 +18,8 @@ struct GemmArgs {
   int Cin, Cout;
   int ks, stride, pad, ups;
   const float* pscale; const float* pshift;  // [zo][Cin] or null
+  int ld_ps;                      // f16x3 only: row pitch of pscale/pshift when the launch covers a channel sub-range of a wider
+                                  //   normalised tensor (0 = Cin)
   int silu;
   const float* w; int ldb; int bT; long long w_zo, w_zi;
   const float* bias;              // [Cout] or null

@@ -33,9 +33,10 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_TBS = 8.0
-# measured on this chip with random operands, bare MFMA stream (scripts/calib/mfma_peak.hip -> profiles/r01_calib_mfma_peak.txt):
-# the power envelope caps v_mfma_f32_32x32x16_f16 at 1.66 PFLOP/s (2.46 with zero operands)
-F16_MFMA_MEASURED_RANDOM_TFLOPS = 1657.0
+# measured on this chip with UNet-like operands, bare MFMA stream (scripts/calib/mfma_energy.hip -> profiles/r02s_calib_mfma_energy.txt):
+# the power envelope caps v_mfma_f32_32x32x16_f16 at 1.62-1.66 PFLOP/s and v_mfma_f32_16x16x32_f16 (the main tile's instruction
+# since r02t) at 1.85-1.89 PFLOP/s; 2.44-2.46 with zero operands
+F16_MFMA_MEASURED_RANDOM_TFLOPS = {"16x16x32": 1870.0, "32x32x16": 1657.0}
 T_EDIT, T_0, N_INV, N_GEN = 500, 999, 40, 40
 
 CELEBA = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16],
@@ -317,7 +318,7 @@ def main():
                 # the kernel issues 3 f16 matrix products per algorithmic (fp32-equivalent) product: its ceiling for
                 # ALGORITHMIC flops is the dense f16 MFMA peak / 3
                 peak = F16_MFMA_PEAK_TFLOPS / 3.0
-                basis = ("dense f16 MFMA 2500 TFLOP/s / 3 v_mfma_f32_32x32x16_f16 per fp32-equivalent product "
+                basis = ("dense f16 MFMA 2500 TFLOP/s / 3 matrix instructions per fp32-equivalent product "
                          "(two-term f16 operand split)")
             else:
                 peak, basis = F32_MFMA_PEAK_TFLOPS, "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"
@@ -327,8 +328,9 @@ def main():
                                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / prof["launches"],
                                "flops_per_launch": prof["flops"] / prof["launches"],
                                "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
-                               "frac_of_measured_mfma_ceiling": (ach / (F16_MFMA_MEASURED_RANDOM_TFLOPS / 3.0)
-                                                                 if prof["family"] == "f16x3" else None),
+                               "frac_of_measured_mfma_ceiling": (
+                                   ach / (F16_MFMA_MEASURED_RANDOM_TFLOPS["16x16x32" if "k32" in prof["kernel"] else "32x32x16"] / 3.0)
+                                   if prof["family"] == "f16x3" else None),
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
         # per-kernel-family table (both bounds, the binding one named per family), from the same HIP-event record
