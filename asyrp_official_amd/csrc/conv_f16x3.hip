@@ -756,9 +756,12 @@ struct K32Cfg {
 //     needs BOTH its 16-channel chunks in LDS at once, so the shortcut phase turns the two halo buffers into ONE centre-only tile
 //     of 32 channels ([8 units][256 pixels][16 B] = 32 KB): raw loads for the next step travel in registers under the matrix
 //     passes, the split + LDS write sits between two barriers (Cin2 % 32 == 0).
-template <bool SC>
+// ABL: profiling-only instantiation (scripts/conv_bench.py): p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the
+//      loop, 4 = no matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
+template <bool SC, bool ABL = false>
 __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const GemmArgs p) {
   using T = K32Cfg;
+  const int abl = ABL ? p.abl : 0;
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE;
   constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -888,6 +891,18 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
   auto mma_step = [&](const char* A, const int a_tm, const int a_lo, const char* B) {
     h8 fa[4], fb[4];
+    if (ABL && (abl & 4)) {   // all 16 fragment reads, no matrix work
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm + hl * a_lo);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + hl * 2 * BN * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
+      }
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm + a_lo);                // x_lo
 #pragma unroll
@@ -951,7 +966,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   const int nsteps = nsteps3 + nsc;
   int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
   for (int s = 0; s < nsteps3; ++s) {
-    if (s + 1 < nsteps) issue_slot(s + 1, (s + 1) & 1);
+    if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
     if (t1 == 9) { t1 = 0; ++c1; }
     const int ky0 = (t0 * 11) >> 5, ky1 = (t1 * 11) >> 5;     // t / 3 for t in 0..8
@@ -966,7 +981,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
     // the halo tile of the chunk the NEXT step's second slice belongs to must be in LDS before the barrier below; its
     // buffer held chunk need-2, last read at least one barrier ago
     const int need = (t0 == 8) ? c0 + 1 : c0;
-    if (need > staged && need < nch) {
+    if (need > staged && need < nch && !(abl & 8)) {
       gload_A(need);
       write_A(need, need & 1);
       staged = need;
@@ -1108,7 +1123,7 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <bool SC>
+template <bool SC, bool ABL = false>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   using T = K32Cfg;
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
@@ -1120,12 +1135,12 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<SC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<SC, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(igemm_f16x3_k32_kernel<SC>, grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<SC, ABL>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
@@ -1169,6 +1184,10 @@ static int auto_tile_x(const GemmArgs& a) {
   if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
   if (M >= 256 && blocks(256, 128) >= 512) return a.ks == 3 ? gemm_main_tile() : XT_256x128;
+  // 32x32 layers (one workgroup per CU at the nominal batch): the K32 form of the main tile still beats the 128x128 tile,
+  // 337 vs 312-317 and 366 vs 321-324 TFLOP/s on 256->256 / 512->256 @32 (profiles/r02w_k32_ablations_tilechoice.txt), and
+  // fuses the 1x1 shortcut; at 16x16 (half the CUs idle) it loses, 213 vs 249
+  if (a.ks == 3 && M >= 1024 && blocks(256, 128) >= 256 && (a.Cin & 31) == 0) return gemm_main_tile();
   // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
   // (measured, profiles/r01_conv_microbench_*.txt); 8x8 layers (M = 64) fall through to 64-pixel tiles
   if (M >= 128 && blocks(128, 128) >= 256) return XT_128x128;
@@ -1249,6 +1268,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.abl) {   // profiling build of the main tile only
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && a.tile == XT_256x128K32 && !a.s0 && (a.Cin & 31) == 0) return launch_k32<false, true>(a, s);
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true>(a, s);
     return hipErrorInvalidValue;
   }

@@ -29,6 +29,27 @@ if __name__ == "__main__":
             ms, tf = run(256, 128, 0, 128, 3, tile=tile, iters=5)
             print(f"tile {tile} 128->128 @256 B={B}: {ms:.3f} ms {tf:.1f} TFLOP/s")
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "one7":      # single configuration on the K32 tile and on the 32x32x16 tile (PMC runs)
+        for tile in (6, 7):
+            ms, tf = run(256, 128, 0, 128, 3, tile=tile, iters=5)
+            print(f"tile {tile} 128->128 @256 B={B}: {ms:.3f} ms {tf:.1f} TFLOP/s")
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "k32abl":    # ablations of the K32 tile + tile choice for the 32^2 / 16^2 layers
+        print(f"-- ablations of the K32 tile, B={B} (2 = no weight LDS-DMA, 4 = no matrix instructions, 8 = no activation staging)")
+        for (H, Ch, C1) in ((256, 128, 0), (256, 128, 128), (64, 256, 0)):
+            for abl in (32, 32 | 2, 32 | 8, 32 | 2 | 8, 32 | 4, 32 | 4 | 2 | 8):
+                ms, tf = run(H, Ch, C1, Ch, 3, tile=7, abl=abl, iters=6)
+                print(f"  {Ch}+{C1}->{Ch} @{H} abl={abl & 31:2d}: {ms:8.3f} ms {tf:7.1f}", flush=True)
+        print("-- tile choice for the 32^2 / 16^2 layers: engine's choice (0) vs 128x128 (2) vs the K32 main tile (7), interleaved")
+        tiles = (0, 2, 7)
+        for (H, Ch, C1, Co) in ((32, 256, 0, 256), (32, 256, 256, 256), (16, 512, 0, 512), (16, 512, 512, 512)):
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    r[t].append(run(H, Ch, C1, Co, 3, tile=t, iters=8)[1])
+            med = {t: sorted(r[t])[2] for t in tiles}
+            print(f"  {Ch}+{C1}->{Co} @{H}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")
