@@ -198,7 +198,9 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  *   *variant = family*100000 + tile*1000 + ksize*100 + stride*10 + transposedB
  *     family 0 = igemm_f32 (tile: 1=128x128, 2=128x64, 3=64x64, 4=128x32),
  *     family 1 = igemm_f16x3 (tile: 1=256x128 4-wave pipelined, 2=128x128, 3=64x128, 4=64x64, 5=256x64,
- *                             6=256x128 8-wave (the default for big 3x3 layers), 12=256x32),
+ *                             6=256x128 8-wave on v_mfma_f32_32x32x16_f16, 7=the same tile on v_mfma_f32_16x16x32_f16
+ *                             (igemm_f16x3_k32_kernel: the default for 3x3 stride-1 layers of 32x32 pixels and more whose
+ *                             channel counts are multiples of 32), 12=256x32),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */
@@ -217,7 +219,8 @@ int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms
  *   upsample: nearest x2 before the conv (:84-85).
  *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0).
  *   conv_math: enum asyrp_conv_math; tile: 0 = the launcher's own choice, else force one tile shape of that
- *   kernel family so every compiled variant can be parity-tested; tile 13 = the taps-in-N kernel of the UNet's last
+ *   kernel family so every compiled variant can be parity-tested (tile 7 falls back to tile 6 when Cin % 32 != 0);
+ *   tile 13 = the taps-in-N kernel of the UNet's last
  *   convolution (csrc/conv_out.hip: 3x3, stride 1, Cout*9 <= 32, GroupNorm + SiLU prologue required). */
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                     const float* weight, const float* bias, int Cout, int ksize, int stride, int upsample,
