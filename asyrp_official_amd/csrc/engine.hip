@@ -759,20 +759,21 @@ static bool skip_plan(const Act& x0, const Act& x1, SkipPlan* pl) {
   return pl->nclean >= 32 && (pl->nclean % 32) == 0;
 }
 // conv1 of a decoder ResnetBlock in a dual-decoder step; *done = false (nothing launched) when the layer does not qualify
-int conv1_shared(Ctx& c, const std::string& p, const Act& x0, const Act& x1, const float* sc, const float* sh, int Cout,
-                 Act* h1, bool* done) {
+// (DDPM: conv1 + the block's timestep projection as chan_add; iDDPM/ADM: in_layers.2, no per-channel vector)
+int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const std::string& bname, const Act& x0, const Act& x1,
+                 const float* sc, const float* sh, int Cout, const float* chan_add, Act* h1, bool* done) {
   asyrp_engine* e = c.e;
   *done = false;
   SkipPlan pl;
   if (!skip_plan(x0, x1, &pl)) return 0;
-  auto it = e->xw.find(p + ".conv1.weight");
+  auto it = e->xw.find(wname);
   if (it == e->xw.end()) return 0;
   const int Cin = x0.C + x1.C, c_clean = x0.C + pl.dirty, H = x0.H, W = x0.W;
   GemmArgs b;
   memset(&b, 0, sizeof b);
   b.Hin = H; b.Win = W; b.Hout = H; b.Wout = W; b.Cout = Cout;
   b.ks = 3; b.stride = 1; b.pad = 1; b.silu = 1; b.ld_ps = Cin;
-  b.w = P(c, p + ".conv1.weight"); b.ldb = Cout;
+  b.w = P(c, wname); b.ldb = Cout;
   b.math = MATH_F16X3; b.cout_pad = it->second.cout_pad;
   b.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
   b.ldo = Cout; b.o_zo = (long long)H * W * Cout; b.ZI = 1; b.Z = c.B;
@@ -802,8 +803,8 @@ int conv1_shared(Ctx& c, const std::string& p, const Act& x0, const Act& x1, con
     part = f->second;
   }
   TRY(new_act(c, Cout, H, W, h1));
-  g.bias = P(c, p + ".conv1.bias");
-  g.chan_add = c.tproj + e->tproj_off.at(p); g.ld_chan_add = e->tproj_total;
+  g.bias = P(c, bname);
+  g.chan_add = chan_add; g.ld_chan_add = e->tproj_total;
   g.resid = part.p; g.ldr = Cout; g.r_zo = part.per_image();
   g.out = h1->p;
   h1->st_nblk = gemm_mblocks(g);
@@ -829,7 +830,9 @@ int resblock(Ctx& c, const std::string& p, const Act& x0, const Act* x1, Act* ou
   TRY(gn(c, x0, x1, p + ".norm1", 1e-6f, &sc1, &sh1, nullptr, nullptr, 0, c.tape ? &mr1 : nullptr));
   Act h1;
   bool shared = false;
-  if (c.skip_share && x1 && !c.tape && e->math == MATH_F16X3) TRY(conv1_shared(c, p, x0, *x1, sc1, sh1, Cout, &h1, &shared));
+  if (c.skip_share && x1 && !c.tape && e->math == MATH_F16X3)
+    TRY(conv1_shared(c, p, p + ".conv1.weight", p + ".conv1.bias", x0, *x1, sc1, sh1, Cout, c.tproj + e->tproj_off.at(p), &h1,
+                     &shared));
   if (!shared)
     TRY(conv(c, x0, x1, p + ".conv1.weight", p + ".conv1.bias", Cout, 3, 1, 0, sc1, sh1, 1,
              c.tproj + e->tproj_off.at(p), nullptr, &h1, true));
@@ -1041,8 +1044,12 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
              &h1, true));
     rups = 1;
   } else {
-    TRY(conv(c, x0, x1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", Cout, 3, 1, 0, sc1, sh1, 1, nullptr, nullptr, &h1,
-             true));
+    bool shared = false;   // dual-decoder steps: the skip half of the decoder blocks' first conv is shared (conv1_shared)
+    if (c.skip_share && x1 && !c.tape && e->math == MATH_F16X3)
+      TRY(conv1_shared(c, p, p + ".in_layers.2.weight", p + ".in_layers.2.bias", x0, *x1, sc1, sh1, Cout, nullptr, &h1, &shared));
+    if (!shared)
+      TRY(conv(c, x0, x1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", Cout, 3, 1, 0, sc1, sh1, 1, nullptr, nullptr, &h1,
+               true));
   }
   e->pool.put(sc1); e->pool.put(sh1);
   // h = GN(h) * (1 + scale) + shift, (scale, shift) = chunk(Linear(SiLU(emb)), 2)  (:290-294)
@@ -1214,6 +1221,7 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   Act h;
   TRY(run_layers_i(c, e->mid_block, hs.back(), nullptr, &h));
   *middle = h;
+  c.skip_share = (index >= 0 && apply_edit && !tape && skip_share_enabled());   // both decoders run: see conv1_shared
   if (index >= 0 && apply_edit && c.dh_in) {   // injected delta_h tensor: unet.py:708-731
     Act h2;
     TRY(new_act(c, h.C, h.H, h.W, &h2));
@@ -1241,6 +1249,9 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     drop(c, h2);
   }
   TRY(decoder_i(c, h, hs, et));
+  c.skip_share = false;
+  for (auto& kv : c.skip_part) drop(c, kv.second);   // (empty unless a pass stopped early)
+  c.skip_part.clear();
   for (auto& a : hs) drop(c, a);
   e->pool.put(c.tproj);
   c.tproj = nullptr;
