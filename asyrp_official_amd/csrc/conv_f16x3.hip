@@ -740,15 +740,25 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// NW waves as WM x WN; a wave owns 64 pixels (4 tile rows of 16) x 128/WN channels = 4 x TN accumulator blocks.
+//   <8, 2>: 256 x 128, the main tile (16 x 16 patch; 74 KB of LDS, two workgroups per CU, 4 waves per SIMD)
+//   <8, 4>: 128 x 128 for the 16 x 16-pixel layers (8 x 16 patch, wave = 64 pixels x 32 channels; 56 KB)
+template <int NW_, int WN_>
 struct K32Cfg {
-  static constexpr int NW = 8, NT = 512, BM = 256, BN = 128, PW = 16, PH = 16, TW = 18, TH = 18;
-  static constexpr int NPIX = TH * TW;                         // 324 halo pixels
-  static constexpr int PLANE = 336;                            // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
+  static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN;
+  static constexpr int BM = WM * 64, BN = 128, PW = 16, PH = WM * 4, TW = PW + 2, TH = PH + 2;
+  static constexpr int NPIX = TH * TW;                         // halo pixels (324 for the main tile)
+  static constexpr int PLANE = (NPIX + 15) / 16 * 16;          // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
   static constexpr int A_BYTES = 4 * PLANE * 16;               // [4 units][PLANE][16 B]
   static constexpr int B_BYTES = BN * 64;                      // one (chunk, tap) weight slice [4 units][BN][16 B]
   static constexpr int SLOT_BYTES = 2 * B_BYTES;               // the two slices of a K = 32 step
   static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
-  static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;   // 74 KB: two workgroups per CU
+  static constexpr int NSC = BM * 4 / NT;                      // shortcut-phase work items per thread
+  static constexpr int NPW = 16 / NW;                          // LDS-DMA pieces per wave and step
+  static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
+  static constexpr int MINW = (2 * NW) / 4;                    // two workgroups per CU
+  static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
+  static_assert(NA <= 2 && NSC <= 2 && NSC >= 1, "staging registers");
 };
 
 // SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
@@ -758,19 +768,19 @@ struct K32Cfg {
 //     passes, the split + LDS write sits between two barriers (Cin2 % 32 == 0).
 // ABL: profiling-only instantiation (scripts/conv_bench.py): p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the
 //      loop, 4 = no matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
-template <bool SC, bool ABL = false>
-__global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const GemmArgs p) {
-  using T = K32Cfg;
+template <class T, bool SC, bool ABL = false>
+__global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
-  constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE;
-  constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU;
+  constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE, WN = T::WN, WM = T::WM, TN = T::TN, BM = T::BM;
+  constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU, NSC = T::NSC;
+  constexpr int WCH = BN / WN;                 // output channels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB)
   char* const As = smem + 2 * SLOT_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int zo = blockIdx.z;
   const int n0 = blockIdx.y * BN;
   int bx = blockIdx.x;
@@ -856,11 +866,11 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
       *reinterpret_cast<h8*>(dst + 2 * PLANE * 16) = lo;
     }
   };
-  // the two weight slices of K-step s are consecutive in the packed image: 16 1-KiB LDS-DMA pieces, two per wave
+  // the two weight slices of K-step s are consecutive in the packed image: 16 1-KiB LDS-DMA pieces, 16 / NW per wave
   auto issue_slot = [&](int s, int slot) {
-    const int u = wave >> 1, part = wave & 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int k = 0; k < T::NPW; ++k) {
+      const int pc = wave + k * T::NW, i = pc >> 3, u = (pc & 7) >> 1, part = pc & 1;
       const char* src = wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
       char* dst = Bs + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -871,13 +881,13 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   const int a_lane = (kh * PLANE + (wm * 4) * TW + r16) * 16;            // + tm * TW * 16 (+ 2 * PLANE * 16 for x_lo) + tap offset
-  const int b_lane = tp * B_BYTES + (kh * BN + wn * 64 + r16) * 16;       // + tn * 256 (+ 2 * BN * 16 for w_lo) + slot
+  const int b_lane = tp * B_BYTES + (kh * BN + wn * WCH + r16) * 16;      // + tn * 256 (+ 2 * BN * 16 for w_lo) + slot
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][TN];
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
@@ -887,47 +897,47 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // one K = 32 step: 16 fragments, 48 matrix instructions; pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
+  // one K = 32 step: 2 * (4 + TN) fragments, 12 * TN matrix instructions (16 and 48 on the main tile); pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
   // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
   auto mma_step = [&](const char* A, const int a_tm, const int a_lo, const char* B) {
-    h8 fa[4], fb[4];
+    h8 fa[4], fb[TN];
     if (ABL && (abl & 4)) {   // all 16 fragment reads, no matrix work
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm + hl * a_lo);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + hl * 2 * BN * 16);
+        for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + hl * 2 * BN * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i % TN]));
       }
       return;
     }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm + a_lo);                // x_lo
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256);                         // w_hi
+    for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256);                         // w_hi
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm);                       // x_hi
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + 2 * BN * 16);           // w_lo
+    for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256 + 2 * BN * 16);           // w_lo
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
   };
 
   // ---- shortcut phase staging: work item = (centre pixel, 8-channel quarter q of the step's 32 raw channels) ----
   const int q = tid & 3;
-  int scoff[2] = {-1, -1};
+  int scoff[NSC];
   auto sc_load = [&](int j) {
     const int chunk = 2 * j + (q >> 1);
     const bool second = (chunk * XKC >= p.sc0);
@@ -935,7 +945,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
     const float* __restrict__ base = second ? p.s1 + (long long)zo * p.s1_zo + (cc - p.sc0) : p.s0 + (long long)zo * p.s0_zo + cc;
     const int ld = second ? p.lds1 : p.lds0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NSC; ++i) {
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
       const int sp = scoff[i];
       if (sp >= 0) {
@@ -949,15 +959,15 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   };
   auto sc_write = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NSC; ++i) {
       const float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                           areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
       h8 hi, lo;
       split8(t, hi, lo);
       const int pix = (tid + i * NT) >> 2;
-      char* dst = As + (q * 256 + pix) * 16;
+      char* dst = As + (q * BM + pix) * 16;
       *reinterpret_cast<h8*>(dst) = hi;
-      *reinterpret_cast<h8*>(dst + 4 * 256 * 16) = lo;
+      *reinterpret_cast<h8*>(dst + 4 * BM * 16) = lo;
     }
   };
 
@@ -990,9 +1000,9 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
     __syncthreads();
   }
   if (SC) {
-    const char* const Asc = As + (kq * 256 + wm * 64 + r16) * 16;
+    const char* const Asc = As + (kq * BM + wm * 64 + r16) * 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NSC; ++i) {
       const int pix = (tid + i * NT) >> 2;
       const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
       scoff[i] = (gy < p.Hout && gx < p.Wout) ? gy * p.Wout + gx : -1;
@@ -1006,7 +1016,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is written; the loads above stay in flight
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      mma_step(Asc, 256, 4 * 256 * 16, Bs + (s & 1) * SLOT_BYTES + b_lane);
+      mma_step(Asc, 256, 4 * BM * 16, Bs + (s & 1) * SLOT_BYTES + b_lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -1018,12 +1028,12 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
   const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
   const bool has_b = (p.bias != nullptr), has_c = (cadd != nullptr);
   const bool full = (n0 + BN <= Cout) && (oy0 + T::PH <= p.Hout) && (ox0 + PW <= p.Wout);
-  double* const red = reinterpret_cast<double*>(smem);   // [4 wave rows][BN][2]; LDS is free after the last barrier
+  double* const red = reinterpret_cast<double*>(smem);   // [WM wave rows][BN][2]; LDS is free after the last barrier
   const bool want_stats = (p.stats != nullptr);
   const int g = lane >> 4;
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int n = n0 + wn * 64 + tn * 16 + r16;
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * WCH + tn * 16 + r16;
     const bool nok = full || (n < Cout);
     const float add = nok ? ((has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f)) : 0.f;
     double s1 = 0.0, s2 = 0.0;
@@ -1054,7 +1064,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
       if (g == 0) {
-        double* d = red + ((size_t)wm * BN + wn * 64 + tn * 16 + r16) * 2;
+        double* d = red + ((size_t)wm * BN + wn * WCH + tn * 16 + r16) * 2;
         d[0] = s1;
         d[1] = s2;
       }
@@ -1066,7 +1076,7 @@ __global__ void __launch_bounds__(K32Cfg::NT, 4) igemm_f16x3_k32_kernel(const Ge
       if (n0 + c < Cout) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WM; ++w) {
           s1 += red[((size_t)w * BN + c) * 2];
           s2 += red[((size_t)w * BN + c) * 2 + 1];
         }
@@ -1123,9 +1133,10 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <bool SC, bool ABL = false>
+using K32Main = K32Cfg<8, 2>;
+using K32Half = K32Cfg<8, 4>;
+template <class T, bool SC, bool ABL = false>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
-  using T = K32Cfg;
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
   const int gy = (a.Cout + T::BN - 1) / T::BN;
   dim3 grid(gx, gy, a.Z), block(T::NT);
@@ -1134,13 +1145,13 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<SC, ABL>),
+  if (T::SMEM > 64 * 1024 && (dev < 0 || dev >= 16 || !attr_set[dev])) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<T, SC, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<SC, ABL>), grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<T, SC, ABL>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
@@ -1190,7 +1201,9 @@ static int auto_tile_x(const GemmArgs& a) {
   if (a.ks == 3 && M >= 1024 && blocks(256, 128) >= 256 && (a.Cin & 31) == 0) return gemm_main_tile();
   // 32x32 / 16x16 layers: 3 taps per barrier on the 128x128 tile beats the narrower tiles even at one workgroup per CU
   // (measured, profiles/r01_conv_microbench_*.txt); 8x8 layers (M = 64) fall through to 64-pixel tiles
-  if (M >= 128 && blocks(128, 128) >= 256) return XT_128x128;
+  // (3x3 layers with channel counts that are multiples of 32 take the 128-pixel form of the K32 kernel: 16x16 layers 256 -> 284,
+  // 266 -> 307 TFLOP/s, profiles/r02z_ab_k32_128px_tile.txt; eff_tile_x falls back to the 32x32x16 tile otherwise)
+  if (M >= 128 && blocks(128, 128) >= 256) return (a.ks == 3 && k32_preferred()) ? XT_128x128K32 : XT_128x128;
   if (M >= 128 && blocks(64, 128) >= 256) return XT_64x128;
   return XT_64x64;
 }
@@ -1205,9 +1218,11 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.stride == 2) return XT_64x128;
   int t = requested_tile_x(a);
   if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
+  if (t == XT_128x128K32 && !k32_ok(a)) t = XT_128x128;
   if (t == XT_256x128W8 && !a.tile && k32_ok(a) && k32_preferred()) t = XT_256x128K32;
   if (is_vec(a)) return t;
-  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_256x32) ? XT_256x128
+  return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32 ||
+          t == XT_256x32) ? XT_256x128
                                                                                                                : XT_64x128;
 }
 
@@ -1217,7 +1232,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
@@ -1225,7 +1240,7 @@ int gemm_mblocks(const GemmArgs& a) {
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32:
       bm = 256; break;
-    case XT_128x128: bm = 128; break;
+    case XT_128x128: case XT_128x128K32: bm = 128; break;
     default: bm = 64;
   }
   if (a.ks == 1) return (a.Hout * a.Wout + bm - 1) / bm;
@@ -1268,13 +1283,14 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (a.abl) {   // profiling build of the main tile only
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true>(a, s);
-    if (a.ks == 3 && a.stride == 1 && a.tile == XT_256x128K32 && !a.s0 && (a.Cin & 31) == 0) return launch_k32<false, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && a.tile == XT_256x128K32 && !a.s0 && (a.Cin & 31) == 0) return launch_k32<K32Main, false, true>(a, s);
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true>(a, s);
     return hipErrorInvalidValue;
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
-    if (tile == XT_256x128K32) return launch_k32<true>(a, s);
+    if (tile == XT_256x128K32) return launch_k32<K32Main, true>(a, s);
+    if (tile == XT_128x128K32) return launch_k32<K32Half, true>(a, s);
     return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
@@ -1287,7 +1303,8 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128K32: return launch_k32<false>(a, s);
+      case XT_256x128K32: return launch_k32<K32Main, false>(a, s);
+      case XT_128x128K32: return launch_k32<K32Half, false>(a, s);
     }
   } else {
     switch (tile) {

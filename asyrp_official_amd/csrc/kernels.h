@@ -57,7 +57,8 @@ enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_12
 // tile ids of the f16x3 family: 1 = 256x128, 4 waves, software-pipelined loop (big 1x1 layers; 3x3 A/B reference);
 // 6 = 256x128, 8 waves, per-tap loop (the big 3x3 layers and their fused shortcut); 12 = conv_out
 enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
-       XT_256x128K32 = 7 /* the 8-wave tile on v_mfma_f32_16x16x32_f16: 3x3 stride 1, Cin % 32 == 0, no fused shortcut */,
+       XT_256x128K32 = 7 /* the 8-wave tile on v_mfma_f32_16x16x32_f16: 3x3 stride 1, Cin % 32 == 0 */,
+       XT_128x128K32 = 8 /* its 128-pixel form (8 x 16 patch, 8 waves of 64 pixels x 32 channels) */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math

@@ -50,6 +50,18 @@ if __name__ == "__main__":
             med = {t: sorted(r[t])[2] for t in tiles}
             print(f"  {Ch}+{C1}->{Co} @{H}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "k32half":   # 16^2 layers: engine's choice vs 128x128 (2) vs the 128-pixel K32 form (8)
+        tiles = (2, 8, 7)
+        print(f"-- A/B interleaved, B={B}: 128x128 tile on 32x32x16 (2) vs 128-pixel K32 (8) vs 256-pixel K32 (7)")
+        for (H, Ch, C1, Co, kw) in ((16, 512, 0, 512, {}), (16, 512, 512, 512, {}), (16, 512, 0, 512, dict(res=1)),
+                                    (32, 256, 0, 256, {}), (32, 256, 256, 256, {}), (8, 512, 0, 512, {})):
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    r[t].append(run(H, Ch, C1, Co, 3, tile=t, iters=10, **kw)[1])
+            med = {t: sorted(r[t])[2] for t in tiles}
+            print(f"  {Ch}+{C1}->{Co} @{H} {kw}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")

@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-RX='igemm_f16x3_k32_kernel'   # both instantiations (plain and fused shortcut) of the main tile
+RX='igemm_f16x3_k32_kernel<asyrp::K32Cfg<8, 2>'   # both instantiations (plain and fused shortcut) of the main tile
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 500 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/$C -o p -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-parity-check > $OUT/$C.log 2>&1

@@ -101,13 +101,13 @@ def test_conv_out_taps_in_n_kernel(Cout, Cin, H, W):
     assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out kernel Cout={Cout} Cin={Cin} {H}x{W}", **TIGHT)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
     """Force each compiled tile shape of the f16x3 family (256x128 4-wave, 128x128, 64x128, 64x64, 256x64, 256x128
     8-wave, 256x128 8-wave on the 16x16x32 instruction) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32
     concatenated channels, 160 output channels (partial N tile)."""
-    if tile in (6, 7) and k == 1:
+    if tile in (6, 7, 8) and k == 1:
         pytest.skip("the 8-wave tiles are compiled for 3x3 convolutions only")
     B, H, W = 2, 40, 24
     x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
@@ -138,7 +138,8 @@ def test_f16x3_every_tile_shape(tile, k):
 
 @pytest.mark.parametrize("tile,k,H,W,Cout,offset", [(0, 3, 16, 16, 64, 0.0), (1, 3, 40, 24, 160, 0.0), (2, 1, 40, 24, 96, 0.0),
                                                     (3, 3, 20, 12, 96, 30.0), (4, 3, 8, 8, 32, 0.0), (6, 3, 32, 32, 128, 5.0),
-                                                    (7, 3, 32, 32, 128, 5.0), (7, 3, 40, 24, 160, 0.0)])
+                                                    (7, 3, 32, 32, 128, 5.0), (7, 3, 40, 24, 160, 0.0), (8, 3, 16, 16, 128, 5.0),
+                                                    (8, 3, 20, 36, 160, 0.0)])
 def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     """The conv epilogue's per-block {sum, sumsq} partials + finalize == GroupNorm of the conv output (incl. partial
     tiles, 3-channel groups that are not lane-aligned, and a large mean offset that would break a naive fp32 E[x^2]-m^2)."""
@@ -198,10 +199,13 @@ def test_f16x3_k32_tile_matches_the_32x32x16_tile(Cin, C0, H, W, Cout, ups):
     if ups:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
     want = res + F.conv2d(x, w, b, padding=1) + ca[:, :, None, None]
-    got7, got6 = run(7), run(6)
+    got7, got6, got8 = run(7), run(6), run(8)
     assert_close(got7, want, what=f"tile 7 {tag}", **TIGHT)
     assert_close(got7, got6, what=f"tile 7 vs tile 6 {tag}", rtol=1e-5, atol=2e-6)
     assert torch.equal(got7, run(7)), "the K32 tile must be deterministic"
+    # the 128-pixel form of the kernel (8 x 16 patch, waves of 64 pixels x 32 channels) issues the same instructions on the same
+    # operands in the same order per accumulator: bit-identical to the 256-pixel form
+    assert torch.equal(got8, got7), "tile 8 must equal tile 7 bitwise"
 
 
 @pytest.mark.parametrize("B,Ch,C0,C1,Cout,H,W", [(1, 64, 64, 32, 64, 16, 16), (2, 128, 128, 128, 128, 40, 24),
