@@ -743,22 +743,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NW waves as WM x WN; a wave owns 64 pixels (4 tile rows of 16) x 128/WN channels = 4 x TN accumulator blocks.
 //   <8, 2>: 256 x 128, the main tile (16 x 16 patch; 74 KB of LDS, two workgroups per CU, 4 waves per SIMD)
 //   <8, 4>: 128 x 128 for the 16 x 16-pixel layers (8 x 16 patch, wave = 64 pixels x 32 channels; 56 KB)
-template <int NW_, int WN_>
+//   <8, 8, 8>: 64 x 128 for the 8 x 8-pixel layers (8 x 8 patch = one image, a 16-row fragment = two patch rows, wave = 64
+//              pixels x 16 channels; 46 KB: three workgroups per CU)
+//   <8, 4, 16, 2>: 64 x 128 at stride 2 (4 x 16 output patch, 9 x 33 halo; DDPM Downsample)
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1>
 struct K32Cfg {
-  static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN;
-  static constexpr int BM = WM * 64, BN = 128, PW = 16, PH = WM * 4, TW = PW + 2, TH = PH + 2;
+  static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
+  static constexpr int PW = PW_, FR = 16 / PW;                 // FR patch rows per 16-row fragment
+  static constexpr int BM = WM * 64, BN = 128, PH = BM / PW, TW = (PW - 1) * STRIDE + 3, TH = (PH - 1) * STRIDE + 3;
   static constexpr int NPIX = TH * TW;                         // halo pixels (324 for the main tile)
   static constexpr int PLANE = (NPIX + 15) / 16 * 16;          // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
   static constexpr int A_BYTES = 4 * PLANE * 16;               // [4 units][PLANE][16 B]
   static constexpr int B_BYTES = BN * 64;                      // one (chunk, tap) weight slice [4 units][BN][16 B]
   static constexpr int SLOT_BYTES = 2 * B_BYTES;               // the two slices of a K = 32 step
   static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
-  static constexpr int NSC = BM * 4 / NT;                      // shortcut-phase work items per thread
+  static constexpr int NSC = (BM * 4 + NT - 1) / NT;           // shortcut-phase work items per thread
   static constexpr int NPW = 16 / NW;                          // LDS-DMA pieces per wave and step
   static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
   static constexpr int MINW = (2 * NW) / 4;                    // two workgroups per CU
   static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
-  static_assert(NA <= 2 && NSC <= 2 && NSC >= 1, "staging registers");
+  static_assert(NA <= 2 && NSC <= 2 && NSC <= NA, "staging registers");
+  static_assert(PW == 16 || PW == 8, "a fragment is one or two patch rows");
 };
 
 // SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
@@ -774,6 +779,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE, WN = T::WN, WM = T::WM, TN = T::TN, BM = T::BM;
   constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU, NSC = T::NSC;
   constexpr int WCH = BN / WN;                 // output channels per wave
+  constexpr int FR = T::FR, STRIDE = T::STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB)
   char* const As = smem + 2 * SLOT_BYTES;
@@ -807,7 +813,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     int off = -2;
     if (u < NU) {
       const int iy = pix / TW, ix = pix - iy * TW;
-      const int gy = oy0 - p.pad + iy, gx = ox0 - p.pad + ix;
+      const int gy = oy0 * STRIDE - p.pad + iy, gx = ox0 * STRIDE - p.pad + ix;
       const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
       off = (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
     }
@@ -880,7 +886,9 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
-  const int a_lane = (kh * PLANE + (wm * 4) * TW + r16) * 16;            // + tm * TW * 16 (+ 2 * PLANE * 16 for x_lo) + tap offset
+  // row r16 of row block tm = patch pixel ((wm * 4 + tm) * FR + r16 / PW, r16 % PW)
+  const int a_lane = (kh * PLANE + ((wm * 4 * FR + r16 / PW) * STRIDE) * TW + (r16 % PW) * STRIDE) * 16;
+  constexpr int A_TM = FR * STRIDE * TW * 16;  // byte pitch between row blocks (+ 2 * PLANE * 16 for x_lo, + the tap offset)
   const int b_lane = tp * B_BYTES + (kh * BN + wn * WCH + r16) * 16;      // + tn * 256 (+ 2 * BN * 16 for w_lo) + slot
 
   f32x4 acc[4][TN];
@@ -948,7 +956,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     for (int i = 0; i < NSC; ++i) {
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
       const int sp = scoff[i];
-      if (sp >= 0) {
+      if (sp >= 0) {   // (-1: outside the image, or no work item)
         const float* src = base + (long long)sp * ld;
         v0 = *reinterpret_cast<const float4*>(src);
         v1 = *reinterpret_cast<const float4*>(src + 4);
@@ -965,6 +973,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       h8 hi, lo;
       split8(t, hi, lo);
       const int pix = (tid + i * NT) >> 2;
+      if (pix >= BM) continue;
       char* dst = As + (q * BM + pix) * 16;
       *reinterpret_cast<h8*>(dst) = hi;
       *reinterpret_cast<h8*>(dst + 4 * BM * 16) = lo;
@@ -984,7 +993,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - 3 * ky1)) * 16;
     const char* A = As + a_lane + (tp ? offA1 : offA0);
     const char* B = Bs + (s & 1) * SLOT_BYTES + b_lane;
-    mma_step(A + 0, TW * 16, 2 * PLANE * 16, B);
+    mma_step(A + 0, A_TM, 2 * PLANE * 16, B);
     // two slices on
     t0 += 2;
     if (t0 >= 9) { t0 -= 9; ++c0; }
@@ -1004,8 +1013,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
     for (int i = 0; i < NSC; ++i) {
       const int pix = (tid + i * NT) >> 2;
-      const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
-      scoff[i] = (gy < p.Hout && gx < p.Wout) ? gy * p.Wout + gx : -1;
+      const int gy = oy0 + pix / PW, gx = ox0 + pix % PW;
+      scoff[i] = (pix < BM && gy < p.Hout && gx < p.Wout) ? gy * p.Wout + gx : -1;
     }
     sc_load(0);   // (the only exposed load of the phase: issuing it under the last 3x3 step costs the main loop 16 live registers)
     for (int j = 0; j < nsc; ++j) {
@@ -1039,13 +1048,13 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
-      const int oy = oy0 + wm * 4 + tm;
       int pixel[4];
       bool ok[4];
       float rv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ox = ox0 + 4 * g + r;
+        const int m = 4 * g + r;                                   // row of the 16 x 16 block
+        const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
         ok[r] = nok && (full || (oy < p.Hout && ox < p.Wout));
         pixel[r] = oy * p.Wout + ox;
         rv[r] = 0.f;
@@ -1135,6 +1144,8 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
 
 using K32Main = K32Cfg<8, 2>;
 using K32Half = K32Cfg<8, 4>;
+using K32Img8 = K32Cfg<8, 8, 8>;
+using K32S2 = K32Cfg<8, 8, 16, 2>;
 template <class T, bool SC, bool ABL = false>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
@@ -1159,6 +1170,9 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
 static bool k32_ok(const GemmArgs& a) {
   if (a.s0 && (a.ups || (a.Cin2 & 31) || a.Cin2 < 32)) return false;   // fused shortcut: an even number of raw slices
   return a.ks == 3 && a.stride == 1 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
+}
+static bool k32s2_ok(const GemmArgs& a) {
+  return a.ks == 3 && a.stride == 2 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
 }
 // A/B switch: ASYRP_MAIN_TILE=6 keeps the 32x32x16 organisation for the automatic choice
 static bool k32_preferred() {
@@ -1205,6 +1219,10 @@ static int auto_tile_x(const GemmArgs& a) {
   // 266 -> 307 TFLOP/s, profiles/r02z_ab_k32_128px_tile.txt; eff_tile_x falls back to the 32x32x16 tile otherwise)
   if (M >= 128 && blocks(128, 128) >= 256) return (a.ks == 3 && k32_preferred()) ? XT_128x128K32 : XT_128x128;
   if (M >= 128 && blocks(64, 128) >= 256) return XT_64x128;
+  // 8x8 layers that are not split over K (engine.hip sets the tile itself when it splits): the 8x8-patch form of the K32 kernel,
+  // 99 -> 96 us on 512->512 (profiles/r03a_ab_k32_8x8_stride2.txt) -- these layers are bound by the fixed latencies of a
+  // 64-pixel workgroup streaming a 1.2 MB weight slab, not by the instruction -- and it can fuse the block's 1x1 shortcut
+  if (a.ks == 3 && M == 64 && a.Hout == 8 && k32_preferred()) return XT_64x128K32;
   return XT_64x64;
 }
 
@@ -1215,10 +1233,11 @@ static int requested_tile_x(const GemmArgs& a) {
 
 // the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
 static int eff_tile_x(const GemmArgs& a) {
-  if (a.stride == 2) return XT_64x128;
+  if (a.stride == 2) return (k32s2_ok(a) && k32_preferred() && a.tile != XT_64x128) ? XT_64x128K32S2 : XT_64x128;
   int t = requested_tile_x(a);
   if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
   if (t == XT_128x128K32 && !k32_ok(a)) t = XT_128x128;
+  if (t == XT_64x128K32 && !k32_ok(a)) t = XT_64x64;
   if (t == XT_256x128W8 && !a.tile && k32_ok(a) && k32_preferred()) t = XT_256x128K32;
   if (is_vec(a)) return t;
   return (t == XT_256x128 || t == XT_128x128 || t == XT_256x64 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32 ||
@@ -1232,11 +1251,12 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
   if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
-  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32);
+  return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32 || t == XT_64x128K32);
 }
 
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
+  if (eff_tile_x(a) == XT_64x128K32S2) return ((a.Hout + K32S2::PH - 1) / K32S2::PH) * ((a.Wout + K32S2::PW - 1) / K32S2::PW);
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32:
       bm = 256; break;
@@ -1291,10 +1311,11 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
     if (tile == XT_256x128K32) return launch_k32<K32Main, true>(a, s);
     if (tile == XT_128x128K32) return launch_k32<K32Half, true>(a, s);
+    if (tile == XT_64x128K32) return launch_k32<K32Img8, true>(a, s);
     return launch_x<X256x128w8_3, true, false, false, true>(a, s);
   }
   if (a.ks == 3) {
-    if (a.stride == 2) return launch_x<X64x128_3s2, true, false, true>(a, s);
+    if (a.stride == 2) return tile == XT_64x128K32S2 ? launch_k32<K32S2, false>(a, s) : launch_x<X64x128_3s2, true, false, true>(a, s);
     switch (tile) {
       case XT_256x128: return launch_x<X256x128_3, true, false, true>(a, s);
       case XT_128x128: return launch_x<X128x128_3, true, false, true>(a, s);
@@ -1305,6 +1326,7 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
       case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
       case XT_256x128K32: return launch_k32<K32Main, false>(a, s);
       case XT_128x128K32: return launch_k32<K32Half, false>(a, s);
+      case XT_64x128K32: return launch_k32<K32Img8, false>(a, s);
     }
   } else {
     switch (tile) {

@@ -2566,8 +2566,8 @@ int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, 
   g.ks = 3; g.stride = 1; g.pad = 1; g.pscale = sc; g.pshift = sh; g.silu = 1;
   g.bias = fb; g.out = yo; g.ldo = Cout; g.o_zo = (long long)HW * Cout; g.ZI = 1; g.Z = B;
   // the main tile: its 16x16x32 form when the channel counts allow it (Ch and C0 + C1 multiples of 32), else the 32x32x16 form
-  // (images of 16 x 16 pixels and less exercise the kernel's 128-pixel form)
-  g.math = MATH_F16X3; g.tile = (HW <= 256) ? XT_128x128K32 : XT_256x128K32; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
+  // (images of 16 x 16 pixels and less exercise the kernel's 128-pixel form, 8 x 8 images its 64-pixel form)
+  g.math = MATH_F16X3; g.tile = (HW <= 64) ? XT_64x128K32 : (HW <= 256) ? XT_128x128K32 : XT_256x128K32; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
   g.alpha = 1.0f / (wscale * f16x3_act_scale());
   g.s0 = a0; g.sc0 = C0; g.lds0 = C0; g.s0_zo = (long long)HW * C0;
   if (x1) { g.s1 = a1; g.sc1 = C1; g.lds1 = C1; g.s1_zo = (long long)HW * C1; }

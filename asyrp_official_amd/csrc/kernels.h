@@ -59,6 +59,8 @@ enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_12
 enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4, XT_256x64 = 5, XT_256x128W8 = 6,
        XT_256x128K32 = 7 /* the 8-wave tile on v_mfma_f32_16x16x32_f16: 3x3 stride 1, Cin % 32 == 0 */,
        XT_128x128K32 = 8 /* its 128-pixel form (8 x 16 patch, 8 waves of 64 pixels x 32 channels) */,
+       XT_64x128K32 = 9 /* 8 x 8 patch (one 8 x 8 image), 8 waves of 64 pixels x 16 channels */,
+       XT_64x128K32S2 = 10 /* stride 2 (DDPM Downsample): 4 x 16 output patch, 8 waves of 64 pixels x 16 channels */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math

@@ -200,7 +200,8 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  *     family 1 = igemm_f16x3 (tile: 1=256x128 4-wave pipelined, 2=128x128, 3=64x128, 4=64x64, 5=256x64,
  *                             6=256x128 8-wave on v_mfma_f32_32x32x16_f16, 7=the same tile on v_mfma_f32_16x16x32_f16
  *                             (igemm_f16x3_k32_kernel: the default for 3x3 stride-1 layers of 32x32 pixels and more whose
- *                             channel counts are multiples of 32), 8=its 128-pixel form (16x16-pixel layers), 12=256x32),
+ *                             channel counts are multiples of 32), 8=its 128-pixel form (16x16-pixel layers), 9=its 8x8-patch form, 10=its stride-2 form,
+ *                             12=256x32),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */

@@ -62,6 +62,26 @@ if __name__ == "__main__":
             med = {t: sorted(r[t])[2] for t in tiles}
             print(f"  {Ch}+{C1}->{Co} @{H} {kw}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "k32small":  # 8x8 layers and the stride-2 convs on their K32 forms
+        print(f"-- A/B interleaved, B={B}: 8x8 layers: engine's choice without K32 (tile 4 / split-K via tile 0*) vs the 8x8-patch K32 form (9)")
+        for (H, Ch, C1, Co, kw) in ((8, 512, 0, 512, {}), (8, 512, 512, 512, {}), (8, 512, 0, 512, dict(res=1))):
+            tiles = (0, 4, 9)
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    r[t].append(run(H, Ch, C1, Co, 3, tile=t, iters=10, **kw)[0] * 1e3)
+            med = {t: sorted(r[t])[2] for t in tiles}
+            print(f"  {Ch}+{C1}->{Co} @{H} {kw}: " + "  ".join(f"t{t} {med[t]:6.1f} us" for t in tiles), flush=True)
+        print("-- stride 2 (Downsample, no prologue): 32x32x16 64x128 tile (3) vs the launcher's choice (0 = K32 stride-2 form)")
+        for (H, Ch) in ((256, 128), (128, 128), (64, 256), (32, 256), (16, 512)):
+            tiles = (3, 0)
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    r[t].append(run(H, Ch, 0, Ch, 3, stride=2, pro=0, tile=t, iters=8)[1])
+            med = {t: sorted(r[t])[2] for t in tiles}
+            print(f"  {Ch}->{Ch} @{H}->{H // 2}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")

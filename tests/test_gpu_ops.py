@@ -101,13 +101,13 @@ def test_conv_out_taps_in_n_kernel(Cout, Cin, H, W):
     assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv_out kernel Cout={Cout} Cin={Cin} {H}x{W}", **TIGHT)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("k", [1, 3])
 def test_f16x3_every_tile_shape(tile, k):
     """Force each compiled tile shape of the f16x3 family (256x128 4-wave, 128x128, 64x128, 64x64, 256x64, 256x128
     8-wave, 256x128 8-wave on the 16x16x32 instruction) on a ragged problem: 40x24 pixels (partial tiles on both axes), 64+32
     concatenated channels, 160 output channels (partial N tile)."""
-    if tile in (6, 7, 8) and k == 1:
+    if tile in (6, 7, 8, 9) and k == 1:
         pytest.skip("the 8-wave tiles are compiled for 3x3 convolutions only")
     B, H, W = 2, 40, 24
     x0 = hash_normal(f"tile.x0.{k}", (B, 64, H, W))
@@ -139,7 +139,7 @@ def test_f16x3_every_tile_shape(tile, k):
 @pytest.mark.parametrize("tile,k,H,W,Cout,offset", [(0, 3, 16, 16, 64, 0.0), (1, 3, 40, 24, 160, 0.0), (2, 1, 40, 24, 96, 0.0),
                                                     (3, 3, 20, 12, 96, 30.0), (4, 3, 8, 8, 32, 0.0), (6, 3, 32, 32, 128, 5.0),
                                                     (7, 3, 32, 32, 128, 5.0), (7, 3, 40, 24, 160, 0.0), (8, 3, 16, 16, 128, 5.0),
-                                                    (8, 3, 20, 36, 160, 0.0)])
+                                                    (8, 3, 20, 36, 160, 0.0), (9, 3, 8, 8, 128, 5.0), (9, 3, 20, 12, 160, 0.0)])
 def test_fused_groupnorm_statistics_epilogue(tile, k, H, W, Cout, offset):
     """The conv epilogue's per-block {sum, sumsq} partials + finalize == GroupNorm of the conv output (incl. partial
     tiles, 3-channel groups that are not lane-aligned, and a large mean offset that would break a naive fp32 E[x^2]-m^2)."""
@@ -206,11 +206,12 @@ def test_f16x3_k32_tile_matches_the_32x32x16_tile(Cin, C0, H, W, Cout, ups):
     # the 128-pixel form of the kernel (8 x 16 patch, waves of 64 pixels x 32 channels) issues the same instructions on the same
     # operands in the same order per accumulator: bit-identical to the 256-pixel form
     assert torch.equal(got8, got7), "tile 8 must equal tile 7 bitwise"
+    assert torch.equal(run(9), got7), "tile 9 (8 x 8 patches, 16 channels per wave) must equal tile 7 bitwise"
 
 
 @pytest.mark.parametrize("B,Ch,C0,C1,Cout,H,W", [(1, 64, 64, 32, 64, 16, 16), (2, 128, 128, 128, 128, 40, 24),
                                                    (1, 32, 48, 0, 160, 20, 36), (2, 64, 48, 48, 192, 36, 20),
-                                                   (1, 96, 32, 0, 128, 16, 16)])
+                                                   (1, 96, 32, 0, 128, 16, 16), (2, 64, 64, 64, 128, 8, 8)])
 def test_fused_shortcut_resblock_tail(B, Ch, C0, C1, Cout, H, W):
     """conv3x3(swish(GN(h))) + nin_shortcut(cat(x0, x1)) in one launch: the shortcut's 1x1 runs as extra single-tap K-chunks
     of the 3x3 conv (partial tiles, two-source concat, Cout not a multiple of the N tile).  Channel counts that are multiples of
@@ -307,6 +308,21 @@ def test_conv3x3_stride2_asymmetric_pad(math):
     for (B, C, H) in [(2, 32, 16), (1, 128, 32), (1, 64, 8)]:
         x, w, b = _mk(B, C, C, H, 3, f"s2.{C}.{H}")
         assert_close(hip_conv(x, w, b, stride=2, math=math), ref_conv(x, w, b, stride=2), what="downsample conv", **TIGHT)
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W", [(2, 32, 128, 16, 16), (1, 128, 128, 64, 64), (2, 96, 160, 40, 24), (1, 64, 64, 8, 8),
+                                          (1, 48, 64, 16, 16)])
+def test_f16x3_stride2_k32_form_matches_the_32x32x16_tile(B, C, Cout, H, W):
+    """DDPM Downsample (3x3, stride 2, pad right/bottom) on the 16x16x32 form of the kernel (4 x 16 output patch, 9 x 33 halo, the
+    launcher's choice when Cin % 32 == 0) against the fp32 reference and against the 32x32x16 stride-2 tile (tile 3): partial
+    patches on both axes, partial N tile, a bias; 48 input channels fall back to the 32x32x16 tile."""
+    x = hash_normal(f"s2k.x.{C}.{H}.{W}", (B, C, H, W))
+    w = hash_uniform(f"s2k.w.{C}.{Cout}", (Cout, C, 3, 3), -1, 1) / (C * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"s2k.b.{Cout}", (Cout,))
+    want = ref_conv(x, w, b, stride=2)
+    got, old = hip_conv(x, w, b, stride=2), hip_conv(x, w, b, stride=2, tile=3)
+    assert_close(got, want, what="stride-2 K32", **TIGHT)
+    assert_close(got, old, what="stride-2 K32 vs tile 3", rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("math", MATHS)
