@@ -16,6 +16,8 @@
 //       staged ONCE and re-used by all 9 taps (LDS holds the (PH+2)x(PW+2) halo).
 //   B (weights, pre-split and pre-packed at load time in exactly the LDS image order):
 //       global_load_lds_dwordx4 (LDS-DMA, no VGPRs) one (chunk,tap) slice [u=4][BN][8 x f16] per K-step, double buffered.
+//   (this header describes the 32x32x16 family; the 3x3 layers whose channel counts are multiples of 32 run on
+//   igemm_f16x3_k32_kernel further down, same data flow, one v_mfma_f32_16x16x32_f16 per two (chunk, tap) slices)
 //   MFMA: per K-step (16 channels of one tap) each wave issues TM*TN*3 v_mfma_f32_32x32x16_f16 from
 //       (TM+TN)*2 ds_read_b128 fragments; "unit-major" LDS layout: B-fragment reads conflict-free, A-fragment reads
 //       conflict-free with the row permutation below (4-wave tiles).
@@ -721,7 +723,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
 
 
 // ---------------------------------------------------------------------------------------------------
-// The 256 x 128 tile of the big 3x3 layers on v_mfma_f32_16x16x32_f16 ("K32").
+// The 3x3 layers on v_mfma_f32_16x16x32_f16 ("K32"): the 256 x 128 main tile and its 128-pixel / 8x8-patch / stride-2 forms.
 // The chip is power-limited under the f16 matrix instructions on non-zero data, so the sustained rate of an instruction stream
 // is set by the ENERGY an instruction costs, not by its issue rate: scripts/calib/mfma_energy.hip measures 1.62 PFLOP/s for
 // v_mfma_f32_32x32x16_f16 against 1.89 PFLOP/s for v_mfma_f32_16x16x32_f16 on the same UNet-like operands (the 16x16x32 form
@@ -745,7 +747,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   <8, 4>: 128 x 128 for the 16 x 16-pixel layers (8 x 16 patch, wave = 64 pixels x 32 channels; 56 KB)
 //   <8, 8, 8>: 64 x 128 for the 8 x 8-pixel layers (8 x 8 patch = one image, a 16-row fragment = two patch rows, wave = 64
 //              pixels x 16 channels; 46 KB: three workgroups per CU)
-//   <8, 4, 16, 2>: 64 x 128 at stride 2 (4 x 16 output patch, 9 x 33 halo; DDPM Downsample)
+//   <8, 8, 16, 2>: 64 x 128 at stride 2 (4 x 16 output patch, 9 x 33 halo, wave = 64 pixels x 16 channels; DDPM Downsample)
 template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
@@ -769,7 +771,7 @@ struct K32Cfg {
 // SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
 //     tensor (s0|s1) (weights appended to the image, as for igemm_f16x3_kernel); two of them make a K = 32 step.  Such a step
 //     needs BOTH its 16-channel chunks in LDS at once, so the shortcut phase turns the two halo buffers into ONE centre-only tile
-//     of 32 channels ([8 units][256 pixels][16 B] = 32 KB): raw loads for the next step travel in registers under the matrix
+//     of 32 channels ([8 units][BM pixels][16 B], 32 KB on the main tile): raw loads for the next step travel in registers under the matrix
 //     passes, the split + LDS write sits between two barriers (Cin2 % 32 == 0).
 // ABL: profiling-only instantiation (scripts/conv_bench.py): p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the
 //      loop, 4 = no matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
