@@ -11,8 +11,9 @@ for TILE in 7 6; do
   python - $TILE > $OUT/run_tile$TILE.txt 2>&1 <<'PY' &
 import sys, time
 sys.path.insert(0, "scripts")
-import conv_bench as cb
 tile = int(sys.argv[1])
+sys.argv[1:] = ["32"]          # conv_bench reads its batch from argv
+import conv_bench as cb
 t0 = time.time()
 while time.time() - t0 < 14.0:
     ms, tf = cb.run(256, 128, 128, 128, 3, tile=tile, iters=40)
