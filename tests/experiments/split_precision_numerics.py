@@ -3,7 +3,7 @@
 Emulates  conv(x, w) ~= conv(x_hi, w_hi) + conv(x_hi, w_lo) + conv(x_lo, w_hi)  with x_hi/x_lo, w_hi/w_lo
 the two-term f16 (or bf16) split of the fp32 operands.  Modes: f32, f16x1, f16x3, bf16x1, bf16x3, and the round-2 candidates for
 cutting matrix work per output: f16x3-cross-e4m3 / f16x3-cross-e2m3 (cross terms on block-scaled fp8 / MX-fp6) and f16x3-wino
-(Winograd F(2x2,3x3) on the split, 2.25x fewer products).  Products of two f16 values are exact in fp32,
+(Winograd F(2x2,3x3) on the split, 2.25x fewer products), f16x3-lo8 / f16x3-lo6 (lo terms kept to 8 / 6 significant bits).  Products of two f16 values are exact in fp32,
 and the CPU conv accumulates in fp32 like the matrix core does, so this is a faithful model of a
 v_mfma_f32_32x32x16_f16 "x3" implicit GEMM.  Run:  python tests/experiments/split_precision_numerics.py [mode]
 """
@@ -96,6 +96,21 @@ def conv_split(x, sd, p, stride=1, padding=0):
         wh, wl = split(w * s, torch.float16)
         y = F.conv2d(xh, wh, None, **kw) + (F.conv2d(cross(xh, 1), cross(wl, 1), None, **kw) +
                                             F.conv2d(cross(xl, 1), cross(wh, 1), None, **kw))
+        return y / s + b[None, :, None, None]
+    if MODE.startswith("f16x3-lo"):
+        # lo terms rounded to N significant bits (scripts/calib/mfma_energy.hip: +1.5 % matrix rate per three bits dropped)
+        nbits = int(MODE[len("f16x3-lo"):])
+        s = 2.0 ** torch.floor(torch.log2(1.0 / w.abs().max())).item()
+        kw = dict(stride=stride, padding=padding)
+        def keep(v):
+            u = v.to(torch.float16).view(torch.int16).to(torch.int32) & 0xFFFF
+            drop = 11 - nbits
+            u = ((u + (1 << (drop - 1))) & ~((1 << drop) - 1)) & 0xFFFF
+            return u.to(torch.int16).view(torch.float16).float()
+        xh, xl = split(x, torch.float16)
+        wh, wl = split(w * s, torch.float16)
+        xl, wl = keep(xl), keep(wl)
+        y = F.conv2d(xh, wh, None, **kw) + (F.conv2d(xh, wl, None, **kw) + F.conv2d(xl, wh, None, **kw))
         return y / s + b[None, :, None, None]
     dt = torch.float16 if MODE.startswith("f16") else torch.bfloat16
     # per-layer power-of-two weight scale so the f16 lo term stays out of the subnormal range
