@@ -27,7 +27,7 @@ class AsyrpConfig(C.Structure):
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
-ABI_VERSION = 6   # include/asyrp.h ASYRP_ABI_VERSION
+ABI_VERSION = 7   # include/asyrp.h ASYRP_ABI_VERSION
 
 _SIGS = {
     "asyrp_abi_version": (C.c_int, []),
@@ -48,6 +48,7 @@ _SIGS = {
     "asyrp_train_forward": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "asyrp_train_backward": (C.c_int, [_P, _P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), _P]),
     "asyrp_train_discard": (None, [_P]),
+    "asyrp_sampler_update": (C.c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "asyrp_device_bytes": (C.c_int64, [_P]),
     "asyrp_profile_table": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "asyrp_profile_enable": (C.c_int, [_P, _I]),

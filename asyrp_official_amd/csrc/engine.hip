@@ -2697,4 +2697,38 @@ int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int he
   return 0;
 }
 
+// Step arithmetic of the vendored samplers (GaussianDiffusion.p_sample / ddim_sample / ddim_reverse_sample,
+// models/guided_diffusion/gaussian_diffusion.py:402-446, 544-630) as one elementwise launch per 32 images: see
+// sampler_update_kernel.  Stateless (no engine): the schedule lives in the caller's float64 tables, which it folds into the
+// per-image rows coef_host[b] = {a, b, p, q, r, lo, hi, clip}.  Asynchronous on `stream`.
+int asyrp_sampler_update(int device, const float* x, const float* model_out, int out_channels, int B, int C, int HW,
+                         const float* coef_host, const float* noise, float* sample, float* pred_xstart, float* log_variance,
+                         void* stream) {
+  if (!x || !model_out || !coef_host || B < 1 || C < 1 || HW < 1) return fail(ASYRP_EINVAL, "bad argument");
+  if (out_channels != C && out_channels != 2 * C) return fail(ASYRP_EINVAL, "model output must have C or 2C channels");
+  if (!sample && !pred_xstart && !log_variance) return fail(ASYRP_EINVAL, "no output requested");
+  if (log_variance && out_channels != 2 * C) return fail(ASYRP_EINVAL, "log_variance needs the learned variance channels");
+  HIPCHK(hipSetDevice(device));
+  const long long per = (long long)C * HW;
+  for (int b0 = 0; b0 < B; b0 += SamplerArgs::MAXB) {
+    SamplerArgs a;
+    memset(&a, 0, sizeof a);
+    a.nb = std::min<int>(SamplerArgs::MAXB, B - b0);
+    a.C = C; a.HW = HW; a.eps_img = (long long)out_channels * HW;
+    a.x = x + b0 * per;
+    a.eps = model_out + b0 * a.eps_img;
+    a.var = (out_channels == 2 * C) ? a.eps + per : nullptr;
+    a.noise = noise ? noise + b0 * per : nullptr;
+    a.out = sample ? sample + b0 * per : nullptr;
+    a.x0 = pred_xstart ? pred_xstart + b0 * per : nullptr;
+    a.logvar = log_variance ? log_variance + b0 * per : nullptr;
+    for (int i = 0; i < a.nb; ++i) {
+      const float* r = coef_host + (size_t)(b0 + i) * 8;
+      a.k[i] = SamplerCoef{r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7] != 0.f ? 1 : 0};
+    }
+    HIPCHK(launch_sampler_update(a, (hipStream_t)stream));
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -165,6 +165,18 @@ struct DdimArgs {
 };
 hipError_t launch_ddim(const DdimArgs& a, hipStream_t s);
 
+// per-image affine sampler update (kernels.hip: sampler_update_kernel); NCHW, all device pointers, `eps`/`var` are channel
+// blocks of one model output whose images are eps_img floats apart
+struct SamplerCoef { float a, b, p, q, r, lo, hi; int clip; };
+struct SamplerArgs {
+  enum { MAXB = 32 };
+  const float* x; const float* eps; const float* var; const float* noise;   // var / noise nullable
+  long long eps_img; int C, HW, nb;
+  float* out; float* x0; float* logvar;                                     // each nullable
+  SamplerCoef k[MAXB];
+};
+hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s);
+
 // ---- training step (backward.hip): data gradients through decoder #2, DeltaBlock parameter gradients ----
 struct ActBwdArgs {
   const float* dA; int ldd;                 // gradient w.r.t. act(GN(x)), [N][HW][ldd]

@@ -927,4 +927,42 @@ hipError_t launch_ddim(const DdimArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// =====================================================================================================
+// Per-image affine sampler update on NCHW tensors (the step arithmetic behind GaussianDiffusion.p_sample / ddim_sample /
+// ddim_reverse_sample, models/guided_diffusion/gaussian_diffusion.py:402-446, 544-630): every one of those updates is
+//     x0  = clamp?(a * x - b * eps)                       (pred_xstart)
+//     out = p * x0 + q * x + r * noise                     (sample, or the posterior mean when there is no noise)
+// with five per-image scalars the host derives from the float64 schedule; for learned-variance networks the noise scale is
+// per element: r * exp(0.5 * (f * hi + (1 - f) * lo)), f = (v + 1) / 2, and that log-variance is written out on request.
+// One chunk of up to SamplerArgs::MAXB images per launch; the coefficients travel in the kernel arguments.
+// =====================================================================================================
+__global__ void sampler_update_kernel(const SamplerArgs a) {
+  const long long per = (long long)a.C * a.HW, total = per * a.nb;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const long long j = i - (long long)b * per;
+    const SamplerCoef k = a.k[b];
+    const float x = a.x[i];
+    const float e = a.eps[(long long)b * a.eps_img + j];
+    float x0 = k.a * x - k.b * e;
+    if (k.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    float r = k.r;
+    if (a.var) {
+      const float f = (a.var[(long long)b * a.eps_img + j] + 1.0f) * 0.5f;
+      const float lv = f * k.hi + (1.0f - f) * k.lo;
+      if (a.logvar) a.logvar[i] = lv;
+      r *= __expf(0.5f * lv);
+    }
+    float o = k.p * x0 + k.q * x;
+    if (a.noise) o += r * a.noise[i];
+    if (a.out) a.out[i] = o;
+    if (a.x0) a.x0[i] = x0;
+  }
+}
+
+hipError_t launch_sampler_update(const SamplerArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(sampler_update_kernel, dim3(ew_blocks((long long)a.nb * a.C * a.HW)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace asyrp

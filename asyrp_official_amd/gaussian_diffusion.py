@@ -1,130 +1,200 @@
-"""Vendored-sampler signatures of the reference (third row): `GaussianDiffusion.p_sample`, `ddim_sample`,
-`ddim_reverse_sample` and `p_mean_variance` of models/guided_diffusion/gaussian_diffusion.py:232-321, 402-446, 544-630
-(the same class is vendored under models/improved_ddpm/), as thin wrappers over the engine-backed UNets.
+"""Sampler signatures of the reference's vendored `GaussianDiffusion` (third row) on the engine.
 
-The reference never calls them, and as vendored they cannot drive its own Asyrp-modified UNets: `p_mean_variance` expects
-`model(x, t)` to return one tensor (:267) while the modified `forward` returns the 4-tuple (et, et_modified, delta_h, middle_h).
-Here the first element (the un-edited eps, with the variance channels when learn_sigma) is used, which is what the upstream
-guided-diffusion code these methods come from would see.  Everything but the model call is elementwise arithmetic on
-[B,3,R,R] tensors with the reference's float64 numpy tables (:135-171), done in torch on the tensors' device.
+The reference carries guided-diffusion's sampler class (models/guided_diffusion/gaussian_diffusion.py; `p_mean_variance`
+:232-321, `p_sample` :402-446, `ddim_sample` :544-592, `ddim_reverse_sample` :594-630) but never calls it.  This module keeps
+those four call signatures and result dictionaries for scripts written against them, with a different construction:
+
+* every one of the updates is affine in (x, pred_xstart, noise) once the timestep is fixed,
+      pred_xstart = clamp?(a*x - b*eps)          sample = p*pred_xstart + q*x + r*noise
+  so the float64 schedule is folded ON THE HOST into one coefficient row (a, b, p, q, r, lo, hi, clip) per image
+  (`SamplerSchedule.rows`), and
+* the tensor arithmetic is ONE elementwise launch of the HIP library (`asyrp_sampler_update`, csrc/kernels.hip) that reads the
+  UNet output in place (eps = channels 0..2, learned-variance channels 3..5) - no table gathers, no intermediate tensors.
+
+The Asyrp-modified UNets return a 4-tuple (et, et_modified, delta_h, middle_h); its first element (the un-edited eps, plus the
+variance channels of learn_sigma networks) is what the upstream sampler code would see and is what is used here.
+There is no CPU path: tensors must live on the GPU, like everywhere else in this package.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import _lib
+from .engine import AsyrpDeviceError
 
-def _extract_into_tensor(arr, timesteps, broadcast_shape):
-    """gaussian_diffusion.py:_extract_into_tensor: float64 table -> float tensor gathered at `timesteps`, broadcastable."""
-    res = torch.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
-    while len(res.shape) < len(broadcast_shape):
-        res = res[..., None]
-    return res.expand(broadcast_shape)
+VAR_TYPES = ("fixed_small", "fixed_large", "learned_range")
+ROW = 8   # floats per coefficient row: a, b, p, q, r, lo, hi, clip
+
+
+class SamplerSchedule:
+    """Float64 diffusion tables and the closed-form coefficient rows derived from them (host only, numpy)."""
+
+    def __init__(self, betas):
+        beta = np.asarray(betas, dtype=np.float64).reshape(-1)
+        if not ((beta > 0).all() and (beta <= 1).all()):
+            raise ValueError("betas must lie in (0, 1]")
+        self.beta = beta
+        self.T = beta.size
+        self.abar = np.cumprod(1.0 - beta)
+        self.abar_prev = np.concatenate(([1.0], self.abar[:-1]))
+        self.abar_next = np.concatenate((self.abar[1:], [0.0]))
+        post = beta * (1.0 - self.abar_prev) / (1.0 - self.abar)            # posterior variance of q(x_{t-1} | x_t, x_0)
+        self.log_post = np.log(np.concatenate((post[1:2], post[1:])))       # its log with entry 0 replaced by entry 1
+        self.log_large = np.log(np.concatenate((post[1:2], beta[1:])))      # "fixed_large": beta_t, same replacement at 0
+
+    def fixed_log_variance(self, var_type, t):
+        return (self.log_large if var_type == "fixed_large" else self.log_post)[t]
+
+    def rows(self, kind, t, *, var_type, clip, eta=0.0, noisy=True):
+        """[B, ROW] float32 rows for integer timesteps `t` ([B] array).
+        kind: 'posterior' (p_sample / p_mean_variance), 'ddim', 'ddim_reverse'."""
+        t = np.asarray(t, dtype=np.int64).reshape(-1)
+        ab = self.abar[t]
+        a = np.sqrt(1.0 / ab)                     # pred_xstart = a*x - b*eps
+        b = np.sqrt(1.0 / ab - 1.0)
+        lo = hi = np.zeros_like(ab)
+        live = (t != 0).astype(np.float64)        # the samplers add no noise at t == 0
+        if kind == "posterior":
+            prev = self.abar_prev[t]
+            p = self.beta[t] * np.sqrt(prev) / (1.0 - ab)
+            q = (1.0 - prev) * np.sqrt(1.0 - self.beta[t]) / (1.0 - ab)
+            if var_type == "learned_range":       # per-element log-variance between lo and hi, evaluated by the kernel
+                r, lo, hi = live, self.log_post[t], np.log(self.beta[t])
+            else:
+                r = live * np.exp(0.5 * self.fixed_log_variance(var_type, t))
+        elif kind in ("ddim", "ddim_reverse"):
+            to = self.abar_prev[t] if kind == "ddim" else self.abar_next[t]
+            sigma = np.zeros_like(ab)
+            if kind == "ddim" and eta != 0.0:
+                sigma = eta * np.sqrt((1.0 - to) / (1.0 - ab)) * np.sqrt(1.0 - ab / to)
+            k = np.sqrt(np.maximum(1.0 - to - sigma ** 2, 0.0))
+            # sample = sqrt(to)*x0 + k*eps', with eps' = (a*x - x0)/b re-derived from the (possibly clamped) x0
+            p = np.sqrt(to) - k / b
+            q = k * a / b
+            r = sigma * live
+        else:
+            raise ValueError(kind)
+        if not noisy:
+            r = np.zeros_like(ab)
+        out = np.stack([a, b, p, q, r, lo, hi, np.full_like(ab, 1.0 if clip else 0.0)], axis=1)
+        return np.ascontiguousarray(out, dtype=np.float32)
+
+
+def _gpu_f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise AsyrpDeviceError(f"{name} must be a CUDA(HIP) tensor - the Asyrp engine has no CPU path")
+    return t.float().contiguous()
+
+
+def sampler_update(x, model_out, rows, *, noise=None, want_sample=True, want_xstart=True, want_log_variance=False):
+    """One `asyrp_sampler_update` launch on x's device and current stream -> (sample, pred_xstart, log_variance)."""
+    x = _gpu_f32(x, "x")
+    model_out = _gpu_f32(model_out, "model output")
+    B, Cx = x.shape[:2]
+    HW = int(np.prod(x.shape[2:]))
+    if model_out.shape[0] != B or tuple(model_out.shape[2:]) != tuple(x.shape[2:]):
+        raise ValueError(f"model output {tuple(model_out.shape)} does not match x {tuple(x.shape)}")
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    assert rows.shape == (B, ROW)
+    if noise is not None:
+        noise = _gpu_f32(noise, "noise")
+        assert noise.shape == x.shape
+    sample = torch.empty_like(x) if want_sample else None
+    xstart = torch.empty_like(x) if want_xstart else None
+    logvar = torch.empty_like(x) if want_log_variance else None
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    lib = _lib.load()
+    _lib.check(lib.asyrp_sampler_update(x.device.index, ptr(x), ptr(model_out), int(model_out.shape[1]), B, Cx, HW,
+                                        rows.ctypes.data_as(C.c_void_p), ptr(noise), ptr(sample), ptr(xstart), ptr(logvar),
+                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return sample, xstart, logvar
 
 
 class GaussianDiffusion:
-    """model_mean_type: 'epsilon' (every reference config).  model_var_type: 'fixed_small' | 'fixed_large' | 'learned_range'
-    (learn_sigma=True networks: AFHQ / ImageNet / MetFaces / CelebA-HQ-P2)."""
+    """Call-compatible with the vendored class for the epsilon-predicting models the reference builds.
+    model_var_type: 'fixed_small' | 'fixed_large' | 'learned_range' (learn_sigma networks)."""
 
     def __init__(self, *, betas, model_mean_type="epsilon", model_var_type="fixed_large", rescale_timesteps=False):
         if model_mean_type != "epsilon":
             raise NotImplementedError("every model of the reference predicts epsilon")
-        if model_var_type not in ("fixed_small", "fixed_large", "learned_range"):
+        if model_var_type not in VAR_TYPES:
             raise NotImplementedError(model_var_type)
         self.model_mean_type, self.model_var_type, self.rescale_timesteps = model_mean_type, model_var_type, rescale_timesteps
-        betas = np.array(betas, dtype=np.float64)
-        assert betas.ndim == 1 and (betas > 0).all() and (betas <= 1).all()
-        self.betas = betas
-        self.num_timesteps = int(betas.shape[0])
-        alphas = 1.0 - betas
-        self.alphas_cumprod = np.cumprod(alphas, axis=0)
-        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
-        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
-        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
-        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
-        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
-        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
-        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
-        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self.schedule = SamplerSchedule(betas)
+        self.num_timesteps = self.schedule.T
+        self.betas, self.alphas_cumprod = self.schedule.beta, self.schedule.abar
 
-    # ---- pieces of the reference class the three samplers use ----------------------------------------------------------
-    def _scale_timesteps(self, t):
-        return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
+    # ---- shared plumbing ------------------------------------------------------------------------------------------------
+    def _model_output(self, model, x, t, model_kwargs):
+        ts = t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
+        out = model(x, ts, **(model_kwargs or {}))
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        want = x.shape[1] * (2 if self.model_var_type == "learned_range" else 1)
+        if out.shape[1] != want:
+            raise ValueError(f"model returned {out.shape[1]} channels, {self.model_var_type} expects {want}")
+        return out
 
-    def _predict_xstart_from_eps(self, x_t, t, eps):
-        return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
-                - _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
+    def _step(self, kind, model, x, t, *, clip_denoised, denoised_fn, model_kwargs, eta=0.0, noise=None, noisy=True,
+              want_log_variance=False):
+        """pred_xstart and the affine update of `kind` in one launch (two when `denoised_fn` has to see pred_xstart)."""
+        tt = t.detach().cpu().numpy()
+        assert tt.shape == (x.shape[0],)
+        out = self._model_output(model, x, t, model_kwargs)
+        rows = self.schedule.rows(kind, tt, var_type=self.model_var_type, clip=clip_denoised, eta=eta, noisy=noisy)
+        if noisy and noise is None and bool((rows[:, 4] != 0).any()):
+            noise = torch.randn_like(x)
+        if not noisy or not bool((rows[:, 4] != 0).any()):
+            noise = None
+        if denoised_fn is None:
+            return (out,) + sampler_update(x, out, rows, noise=noise, want_log_variance=want_log_variance)
+        # x0 first (unclamped), the callback, then the update with x0 handed in as if it were the model output: a = 0, b = -1
+        raw = rows.copy()
+        raw[:, 7] = 0.0
+        _, x0, logvar = sampler_update(x, out, raw, want_sample=False, want_log_variance=want_log_variance)
+        x0 = denoised_fn(x0)
+        rows2 = rows.copy()
+        rows2[:, 0], rows2[:, 1] = 0.0, -1.0
+        carrier = x0 if out.shape[1] == x.shape[1] else torch.cat([x0, out[:, x.shape[1]:]], dim=1)
+        sample, x0, _ = sampler_update(x, carrier, rows2, noise=noise)
+        return out, sample, x0, logvar
 
-    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
-        return ((_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
-                / _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
-
-    def q_posterior_mean_variance(self, x_start, x_t, t):
-        mean = (_extract_into_tensor(self.posterior_mean_coef1, t, x_t.shape) * x_start
-                + _extract_into_tensor(self.posterior_mean_coef2, t, x_t.shape) * x_t)
-        return (mean, _extract_into_tensor(self.posterior_variance, t, x_t.shape),
-                _extract_into_tensor(self.posterior_log_variance_clipped, t, x_t.shape))
-
-    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
-        """gaussian_diffusion.py:232-321.  `t` is an integer tensor [B]."""
-        model_kwargs = model_kwargs or {}
-        B, C = x.shape[:2]
-        assert t.shape == (B,)
-        out = model(x, self._scale_timesteps(t), **model_kwargs)
-        model_output = out[0] if isinstance(out, (tuple, list)) else out       # Asyrp UNets return (et, et_mod, delta_h, middle_h)
+    def _variance_maps(self, x, t, logvar):
         if self.model_var_type == "learned_range":
-            assert model_output.shape == (B, C * 2, *x.shape[2:])
-            model_output, model_var_values = torch.split(model_output, C, dim=1)
-            min_log = _extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
-            max_log = _extract_into_tensor(np.log(self.betas), t, x.shape)
-            frac = (model_var_values + 1) / 2
-            model_log_variance = frac * max_log + (1 - frac) * min_log
-            model_variance = torch.exp(model_log_variance)
-        else:
-            var, logvar = {
-                "fixed_large": (np.append(self.posterior_variance[1], self.betas[1:]),
-                                np.log(np.append(self.posterior_variance[1], self.betas[1:]))),
-                "fixed_small": (self.posterior_variance, self.posterior_log_variance_clipped),
-            }[self.model_var_type]
-            model_variance = _extract_into_tensor(var, t, x.shape)
-            model_log_variance = _extract_into_tensor(logvar, t, x.shape)
-        pred_xstart = self._predict_xstart_from_eps(x_t=x, t=t, eps=model_output)
-        if denoised_fn is not None:
-            pred_xstart = denoised_fn(pred_xstart)
-        if clip_denoised:
-            pred_xstart = pred_xstart.clamp(-1, 1)
-        model_mean, _, _ = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
-        return {"mean": model_mean, "variance": model_variance, "log_variance": model_log_variance, "pred_xstart": pred_xstart}
+            return torch.exp(logvar), logvar
+        lv = torch.from_numpy(self.schedule.fixed_log_variance(self.model_var_type, t.detach().cpu().numpy())).float().to(x.device)
+        lv = lv.view(-1, *([1] * (x.dim() - 1))).expand(x.shape)
+        return torch.exp(lv), lv
 
-    # ---- the three vendored sampler signatures -------------------------------------------------------------------------
+    # ---- the vendored signatures ----------------------------------------------------------------------------------------
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """:232-321 -> {"mean", "variance", "log_variance", "pred_xstart"}; `t` is an integer tensor [B]."""
+        _, mean, x0, logvar = self._step("posterior", model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                         model_kwargs=model_kwargs, noisy=False,
+                                         want_log_variance=self.model_var_type == "learned_range")
+        var, logvar = self._variance_maps(x, t, logvar)
+        return {"mean": mean, "variance": var, "log_variance": logvar, "pred_xstart": x0}
+
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
-        """:402-446.  `noise` (extra keyword) replaces torch.randn_like for reproducible comparisons."""
+        """:402-446 -> {"sample", "pred_xstart"}.  `noise` (extra keyword) stands in for torch.randn_like."""
         if cond_fn is not None:
             raise NotImplementedError("classifier guidance (cond_fn) is not part of the Asyrp path")
-        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
-        noise = torch.randn_like(x) if noise is None else noise
-        nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
-        sample = out["mean"] + nonzero_mask * torch.exp(0.5 * out["log_variance"]) * noise
-        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+        _, sample, x0, _ = self._step("posterior", model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                      model_kwargs=model_kwargs, noise=noise)
+        return {"sample": sample, "pred_xstart": x0}
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0, noise=None):
-        """:544-592."""
+        """:544-592 -> {"sample", "pred_xstart"}."""
         if cond_fn is not None:
             raise NotImplementedError("classifier guidance (cond_fn) is not part of the Asyrp path")
-        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
-        eps = self._predict_eps_from_xstart(x, t, out["pred_xstart"])
-        alpha_bar = _extract_into_tensor(self.alphas_cumprod, t, x.shape)
-        alpha_bar_prev = _extract_into_tensor(self.alphas_cumprod_prev, t, x.shape)
-        sigma = eta * torch.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar)) * torch.sqrt(1 - alpha_bar / alpha_bar_prev)
-        noise = torch.randn_like(x) if noise is None else noise
-        mean_pred = out["pred_xstart"] * torch.sqrt(alpha_bar_prev) + torch.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
-        nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
-        return {"sample": mean_pred + nonzero_mask * sigma * noise, "pred_xstart": out["pred_xstart"]}
+        _, sample, x0, _ = self._step("ddim", model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                      model_kwargs=model_kwargs, eta=float(eta), noise=noise)
+        return {"sample": sample, "pred_xstart": x0}
 
     def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
-        """:594-630 (deterministic reverse ODE step x_t -> x_{t+1})."""
-        assert eta == 0.0, "Reverse ODE only for deterministic path"
-        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
-        eps = ((_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x.shape) * x - out["pred_xstart"])
-               / _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x.shape))
-        alpha_bar_next = _extract_into_tensor(self.alphas_cumprod_next, t, x.shape)
-        mean_pred = out["pred_xstart"] * torch.sqrt(alpha_bar_next) + torch.sqrt(1 - alpha_bar_next) * eps
-        return {"sample": mean_pred, "pred_xstart": out["pred_xstart"]}
+        """:594-630 -> {"sample", "pred_xstart"}: the deterministic x_t -> x_{t+1} step."""
+        if eta != 0.0:
+            raise ValueError("the reverse ODE step is deterministic (eta must be 0)")
+        _, sample, x0, _ = self._step("ddim_reverse", model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                      model_kwargs=model_kwargs, noisy=False)
+        return {"sample": sample, "pred_xstart": x0}

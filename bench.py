@@ -38,6 +38,7 @@ HBM_PEAK_TBS = 8.0
 # since r02t) at 1.85-1.89 PFLOP/s; 2.44-2.46 with zero operands
 F16_MFMA_MEASURED_RANDOM_TFLOPS = {"16x16x32": 1870.0, "32x32x16": 1657.0}
 T_EDIT, T_0, N_INV, N_GEN = 500, 999, 40, 40
+CHECK_DUAL, CHECK_INV = (999, 973), (0, 25)     # (t, t_next) of the two steps cross-checked against the CPU side
 
 CELEBA = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16],
               in_channels=3, resolution=256)   # /root/reference/configs/celeba.yml:13-25
@@ -105,7 +106,7 @@ def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=
     host, else the oracle restatement (kind="port"), timed on a bounded sample: B=1, 4 inversion steps + 4 Asyrp steps
     (dual decoder, as the reference executes them), extrapolated linearly to the 39 + 40 steps of one edit.
     Thread count: the best of {16, 32, 64} threads on one warm forward each (one thread per visible core is far slower on
-    the 256-core GPU hosts: 102 s per forward vs 0.93 s at 16 threads, measured r02a).  Also returns the CPU result of the first inversion step on `x_check` for the parity check."""
+    the 256-core GPU hosts: 102 s per forward vs 0.93 s at 16 threads, measured r02a).  Also returns the CPU results of one dual-decoder Asyrp step and of the first inversion step on `x_check` for the parity check."""
     kind, step = _cpu_step_fn(model_cpu_sd, betas, family, learn_sigma)
     avail = len(os.sched_getaffinity(0))
     g = torch.Generator().manual_seed(1234)
@@ -133,7 +134,12 @@ def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=
     per_image = (N_INV - 1) * t_inv + N_GEN * t_gen
     check = None
     if x_check is not None:
-        check = step(x_check, one * 0.0, one * 25.0, eta=0)[0]
+        # the CPU side of bench.py's parity_check: a dual-decoder Asyrp step (t >= t_edit, DeltaBlock active, second decoder) and
+        # the first inversion step, on the images handed in (rows 0 and B-1 of the GPU batch)
+        ones = torch.ones(x_check.shape[0])
+        check = {"dual": step(x_check, ones * float(CHECK_DUAL[0]), ones * float(CHECK_DUAL[1]), eta=0.0, index=0, t_edit=T_EDIT,
+                              hs_coeff=(1.0, 1.0)),
+                 "inversion": step(x_check, ones * float(CHECK_INV[0]), ones * float(CHECK_INV[1]), eta=0)}
     res = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": kind,
            "sample": f"B=1: {len(inv_pairs)} inversion + {len(gen_pairs)} dual-decoder Asyrp steps timed ({t_inv:.2f} s, "
                      f"{t_gen:.2f} s per step), extrapolated to {N_INV - 1}+{N_GEN} steps; threads chosen by one warm forward each: "
@@ -266,7 +272,8 @@ def main():
 
     # ---- parity at the benchmarked configuration (outside the timed region) ----------------------------------------
     # (1) batch invariance: images 0 and B-1 edited ALONE (B=1) must equal their rows of the batched result bit for bit
-    # (2) (N=1, with the CPU baseline) the first inversion step of image 0 inside the full batch vs the CPU reference/oracle
+    # (2) (N=1, with the CPU baseline) a dual-decoder Asyrp step with t >= t_edit (DeltaBlock + second decoder + skip sharing) and
+    #     the first inversion step, images 0 and B-1 computed inside the full batch, all four outputs vs the CPU reference/oracle
     parity = None
     if not a.no_parity_check:
         diffs = {}
@@ -288,7 +295,14 @@ def main():
     phases = {"inversion_step": phase_ms(486, 512),
               "generation_step_t>=t_edit(dual decoder)": phase_ms(742, 717, index=0, apply_edit=True, hs_coeff=(1.0, 1.0)),
               "generation_step_t<t_edit": phase_ms(256, 230, index=0, apply_edit=False, hs_coeff=(1.0, 1.0))}
-    first_step_gpu = eng.ddim_step(x0, 0, 25, learn_sigma=learn_sigma)[0][0:1].cpu() if rank == 0 else None
+    # GPU side of the CPU cross-check, computed INSIDE the full batch: rows 0 and B-1 of a dual-decoder step and of an inversion step
+    chk_rows = sorted({0, B - 1})
+    gpu_check = None
+    if rank == 0 and not a.no_parity_check:
+        pick = lambda outs: [o[chk_rows].cpu() if o is not None else None for o in outs]   # noqa: E731
+        gpu_check = {"dual": pick(eng.ddim_step(x0, CHECK_DUAL[0], CHECK_DUAL[1], learn_sigma=learn_sigma, index=0, apply_edit=True,
+                                                hs_coeff=(1.0, 1.0))),
+                     "inversion": pick(eng.ddim_step(x0, CHECK_INV[0], CHECK_INV[1], learn_sigma=learn_sigma))}
 
     rc = 0
     if rank == 0:
@@ -368,16 +382,30 @@ def main():
                 res["roofline"]["traffic_note"] = tr.get("note", "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) from the "
                                                          f"committed PMC passes ({tr['round']}); compare with algorithmic_bytes_per_launch")
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"], cpu_first = cpu_baseline(cpu_sd, betas, family, learn_sigma, x_check=x0_cpu[0:1])
-            if parity is not None and cpu_first is not None:
-                err = (first_step_gpu - cpu_first).abs()
-                ok = bool((err <= 1e-4 + 1e-3 * cpu_first.abs()).all())
-                parity["first_step_vs_cpu_" + res["cpu_baseline"]["kind"]] = {
-                    "what": f"xt_next of inversion step t=0->25, image 0 computed inside the B={B} batch on the GPU vs the CPU "
-                            f"{res['cpu_baseline']['kind']} on the same x0", "within_rtol1e-3_atol1e-4": ok,
-                    "max_abs_err": float(err.max()), "mean_abs_err": float(err.mean())}
-                if not ok:
-                    rc = 1
+            res["cpu_baseline"], cpu_chk = cpu_baseline(cpu_sd, betas, family, learn_sigma,
+                                                         x_check=x0_cpu[chk_rows] if gpu_check is not None else None)
+            if parity is not None and cpu_chk is not None:
+                kind = res["cpu_baseline"]["kind"]
+                ab = (1.0 - betas).cumprod(0)
+                for which, (t_, tn_) in (("dual", CHECK_DUAL), ("inversion", CHECK_INV)):
+                    entry = {"what": f"{'dual-decoder Asyrp step (index=0, t_edit=%d, DeltaBlock active)' % T_EDIT if which == 'dual' else 'inversion step'} "
+                                     f"t={t_}->{tn_}, images {chk_rows} computed inside the B={B} batch on the GPU vs the CPU {kind} "
+                                     "on the same x; rtol 1e-3 / atol 1e-4 (x0_t: atol x 1/sqrt(alpha_bar_t), it divides eps by that)",
+                             "outputs": {}}
+                    ok_all = True
+                    for name, gv, cv in zip(("xt_next", "x0_t", "delta_h", "middle_h"), gpu_check[which], cpu_chk[which]):
+                        if gv is None or cv is None:
+                            continue
+                        atol = 1e-4 * (float(ab[t_]) ** -0.5 if name == "x0_t" else 1.0)
+                        err = (gv - cv).abs()
+                        ok = bool((err <= atol + 1e-3 * cv.abs()).all())
+                        ok_all &= ok
+                        entry["outputs"][name] = {"max_abs_err": float(err.max()), "mean_abs_err": float(err.mean()),
+                                                  "ref_abs_max": float(cv.abs().max()), "atol": atol, "within_tolerance": ok}
+                    entry["within_tolerance"] = ok_all
+                    parity[f"{which}_step_vs_cpu_{kind}"] = entry
+                    if not ok_all:
+                        rc = 1
         if parity is not None:
             res["parity_check"] = parity
             if not parity["batch_invariance_bitwise"]:

@@ -76,7 +76,7 @@ typedef struct asyrp_config {
 typedef struct asyrp_engine asyrp_engine;
 
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
-#define ASYRP_ABI_VERSION 6
+#define ASYRP_ABI_VERSION 7
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */
@@ -185,6 +185,19 @@ void asyrp_train_discard(asyrp_engine* e);
 /* DDPM.get_temb (models/ddpm/diffusion.py:464-470): t [B] float timesteps (device) -> temb [B, 4*ch] (device).
  * For the iDDPM family: time_embed(timestep_embedding(t)) (models/improved_ddpm/unet.py:688). */
 int asyrp_get_temb(asyrp_engine* e, const float* t, int B, float* temb_out, void* stream);
+
+/* ---- vendored sampler signatures (never called by the reference) --------------------------------------------
+ * The step arithmetic of GaussianDiffusion.p_sample / ddim_sample / ddim_reverse_sample / p_mean_variance
+ * (models/guided_diffusion/gaussian_diffusion.py:232-321, 402-446, 544-630) in one elementwise launch.  Each of those updates is
+ *     pred_xstart = clamp?(a*x - b*eps),   sample = p*pred_xstart + q*x + r*noise
+ * with per-image scalars the caller derives from its float64 schedule tables; coef_host is [B][8] floats
+ * {a, b, p, q, r, lo, hi, clip}.  model_out [B,out_channels,H,W]: eps = channels 0..C-1; when out_channels == 2C the channels
+ * C..2C-1 are the learned variance interpolation v and the noise scale becomes r*exp(0.5*lv), lv = f*hi + (1-f)*lo,
+ * f = (v+1)/2 (:254-262), written to log_variance [B,C,H,W] on request.  x, noise (nullable), sample, pred_xstart
+ * (nullable each) are [B,C,H,W] NCHW device tensors.  Stateless; asynchronous on `stream`. */
+int asyrp_sampler_update(int device, const float* x, const float* model_out, int out_channels, int B, int C, int HW,
+                         const float* coef_host, const float* noise, float* sample, float* pred_xstart, float* log_variance,
+                         void* stream);
 
 /* Bytes of device memory held by the engine (weights + workspace). */
 int64_t asyrp_device_bytes(const asyrp_engine* e);

@@ -12,6 +12,9 @@ and records reference outputs as .npz fixtures next to this script:
   config1_celeba_smiling.npz   BASELINE config 1 end to end: CelebA-HQ DDPM + the shipped `smiling` DeltaBlock, B=1,
                    full 39 + 40 steps (t_addnoise = 0 and 167), per-step tensors for teacher-forced parity at full size
   config3_afhq_dog_happy.npz   BASELINE config 3 generation phase: AFHQ iDDPM + the shipped `dog_happy` DeltaBlock
+  config4_church_gothic.npz    BASELINE config 4's model: LSUN-church DDPM + the shipped `church_gothic` DeltaBlock, t_edit=370,
+                   three teacher-forced steps at full size
+  imagenet_adm.npz BASELINE config 5's model at full size: i_DDPM('IMAGENET'), B=1, one dual-decoder forward
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; ~1 min on 8 cores)
 """
@@ -532,6 +535,82 @@ def run_vendored_samplers(out):
     print("wrote", out, sorted(g)[:6], "...", len(g), "tensors")
 
 
+def imagenet_state_dict():
+    """Seeded weights for i_DDPM('IMAGENET') (553.8 M parameters): uniform, fan-in scaled (norm weights around 1), from ONE CPU
+    generator stream so the GPU test can regenerate them; the probe stored in the fixture pins that stream."""
+    from oracle.iddpm import IMAGENET, iddpm_param_shapes
+    gen = torch.Generator().manual_seed(77)
+    shapes = iddpm_param_shapes(IMAGENET, n_delta=1)
+    sd = {}
+    for k, shp in shapes.items():
+        wk = k[:-len(".bias")] + ".weight" if k.endswith(".bias") else k
+        ws = shapes.get(wk, shp)
+        if len(ws) == 1:
+            sd[k] = (1.0 if k.endswith(".weight") else 0.0) + 0.1 * (2 * torch.rand(shp, generator=gen) - 1)
+        else:
+            fan_in = 1
+            for d in ws[1:]:
+                fan_in *= d
+            sd[k] = (2 * torch.rand(shp, generator=gen) - 1) / fan_in ** 0.5
+    x = torch.randn((1, 3, 256, 256), generator=gen)
+    return sd, x
+
+
+def run_imagenet(out):
+    """BASELINE config 5 at full size through the REFERENCE: i_DDPM('IMAGENET') as the reference's own factory builds it
+    (models/improved_ddpm/script_util.py:25-42,105-106), B=1, one dual-decoder forward (index=0, t >= t_edit)."""
+    from models.improved_ddpm.script_util import i_DDPM
+    torch.set_num_threads(os.cpu_count())
+    sd, x = imagenet_state_dict()
+    m = i_DDPM("IMAGENET")
+    m.setattr_layers(1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval()
+    g = {}
+    with torch.no_grad():
+        et, em, dh, mh = m(x, torch.ones(1) * 700.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
+    g["probe.x"] = x[0, 0, 0, :8].clone()
+    g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_config4(out):
+    """BASELINE config 4's model through the REFERENCE: the LSUN-church DDPM (configs/church.yml has the CelebA-HQ model block)
+    with hash base weights (seed 4004) + the SHIPPED `church_gothic` DeltaBlock
+    (checkpoint/church_gothic_LC_church_outdoor_t999_ninv40_ngen40_0.pth["0"]), t_edit = 370 (utils/t_edit_dic.py:3), B=1.
+    Three teacher-forced steps of the 40-step generation sequence from seeded x_t: the first step (999 -> 973), the last
+    edited step (384 -> 358: 384 >= 370) and the first un-edited one (358 -> 333)."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=4004)
+    ck = torch.load(os.path.join(REF, "checkpoint", "church_gothic_LC_church_outdoor_t999_ninv40_ngen40_0.pth"),
+                    map_location="cpu", weights_only=False)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    m = ref_model(CELEBA, sd, n_delta=1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", eta=0.0, index=0, t_edit=370, hs_coeff=(1.0, 1.0))
+    one = torch.ones(1)
+    g = {}
+    with torch.no_grad():
+        for t, tn in ((999, 973), (384, 358), (358, 333)):
+            x = hash_normal(f"config4.x{t}", (1, 3, 256, 256), seed=4004)
+            xn, x0t, dh, _ = denoising_step(x, t=one * t, t_next=one * tn, **kw)
+            g[f"gen{t}.xt_next"], g[f"gen{t}.x0_t"] = xn.clone(), x0t.clone()
+            if t >= 370:
+                g[f"gen{t}.delta_h"] = dh.clone()
+            else:
+                assert dh is None
+    for k, v in sd.items():                               # the shipped DeltaBlock itself: /root/reference is not on the GPU box
+        if k.startswith("layer_0."):
+            g["param." + k] = v.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -545,7 +624,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers", "imagenet", "config4"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
@@ -571,3 +650,7 @@ if __name__ == "__main__":
         run_config1_tame(os.path.join(HERE, "config1_celeba_tame.npz"))
     if a.only in (None, "config3"):
         run_config3(os.path.join(HERE, "config3_afhq_dog_happy.npz"))
+    if a.only in (None, "imagenet"):
+        run_imagenet(os.path.join(HERE, "imagenet_adm.npz"))
+    if a.only in (None, "config4"):
+        run_config4(os.path.join(HERE, "config4_church_gothic.npz"))

@@ -163,3 +163,31 @@ def test_config3_afhq_teacher_forced_and_free_running():
     st = err_stats(x_edit, g["x_edit"])
     print("config3 free-running x_edit", st)
     assert st["max_abs"] <= 3e-4 * max(1.0, st["ref_absmax"]) and st["frac_outside"] <= 0.02
+
+
+def test_config4_church_gothic_teacher_forced_steps():
+    """BASELINE config 4's model at full size: the LSUN-church DDPM (configs/church.yml = the CelebA-HQ model block) with the SHIPPED
+    `church_gothic` DeltaBlock, t_edit = 370 (utils/t_edit_dic.py:3), against steps executed by the reference itself
+    (tests/golden/make_golden.py run_config4): first step, last edited step (384 >= 370), first un-edited step."""
+    g = _need("config4_church_gothic.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=4004)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    m = hip_model(CELEBA, sd, 1, max_batch=1)
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    ek = dict(index=0, hs_coeff=(1.0, 1.0))
+    eng = None
+    for t, tn in ((999, 973), (384, 358), (358, 333)):
+        x = hash_normal(f"config4.x{t}", (1, 3, 256, 256), seed=4004).cuda()
+        eng = eng or m._ready_engine(x)
+        xn, x0t, dh, _ = eng.ddim_step(x, t, tn, apply_edit=(t >= 370), **ek)     # the caller evaluates t[0] >= t_edit
+        if t >= 370:
+            print(f"config4 t={t} delta_h", err_stats(dh, g[f"gen{t}.delta_h"]))
+            assert_close(dh, g[f"gen{t}.delta_h"], what=f"t={t} delta_h (shipped church_gothic DeltaBlock)")
+        else:
+            assert dh is None
+        print(f"config4 t={t} xt_next", err_stats(xn, g[f"gen{t}.xt_next"]))
+        assert_close(xn, g[f"gen{t}.xt_next"], what=f"t={t} xt_next")
+        assert_close(x0t, g[f"gen{t}.x0_t"], atol=1e-4 * _amp(b, t), what=f"t={t} x0_t")

@@ -160,10 +160,9 @@ def test_imagenet_style_structure_small():
         assert_close(got, g2[name], what=name)
 
 
-def test_imagenet_adm_full_size_forward_vs_oracle():
-    """i_DDPM('IMAGENET') (553.8 M params, 1024-ch bottleneck, attention T=1024/256/64 with 64-ch heads), B=1, against the
-    CPU oracle on the same seeded weights (the oracle is pinned by the small reference fixtures)."""
-    from asyrp_official_amd import i_DDPM
+def imagenet_weights():
+    """The seeded i_DDPM('IMAGENET') weights + input of tests/golden/make_golden.py:imagenet_state_dict (one CPU generator
+    stream, regenerated here; the fixture's probes pin it)."""
     from oracle.iddpm import IMAGENET
     gen = torch.Generator().manual_seed(77)
     sd = {}
@@ -178,15 +177,25 @@ def test_imagenet_adm_full_size_forward_vs_oracle():
             for d in ws[1:]:
                 fan_in *= d
             sd[k] = (2 * torch.rand(shp, generator=gen) - 1) / fan_in ** 0.5
+    x = torch.randn((1, 3, 256, 256), generator=gen)
+    return sd, x
+
+
+def test_imagenet_adm_full_size_forward_vs_reference():
+    """BASELINE config 5's model: i_DDPM('IMAGENET') (553.8 M params, 1024-ch bottleneck, attention T=1024/256/64 with 64-ch
+    heads), B=1, one dual-decoder forward against the output of the REFERENCE's own i_DDPM('IMAGENET')
+    (tests/golden/imagenet_adm.npz, make_golden.py run_imagenet; the oracle is checked against the same fixture on the CPU)."""
+    from asyrp_official_amd import i_DDPM
+    g = load_golden("imagenet_adm.npz")
+    sd, x = imagenet_weights()
+    assert torch.equal(x[0, 0, 0, :8], g["probe.x"]) and torch.equal(sd["out.2.weight"].reshape(-1)[:8], g["probe.w"]), \
+        "CPU generator stream differs from the fixture's"
     m = i_DDPM("IMAGENET", max_batch=1)
     m.setattr_layers(1)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
-    x = torch.randn((1, 3, 256, 256), generator=gen)
     t = torch.ones(1) * 700.0
     et, em, dh, mh = m(x.cuda(), t.cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
-    with torch.no_grad():
-        w_et, w_em, w_dh, w_mh = iddpm_forward(sd, IMAGENET, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
-    for name, got, want in (("et", et, w_et), ("et_mod", em, w_em), ("delta_h", dh, w_dh), ("middle_h", mh, w_mh)):
-        print(name, err_stats(got, want))
-        assert_close(got, want, what=name)
+    for name, got in (("et", et), ("et_mod", em), ("delta_h", dh), ("middle_h", mh)):
+        print(name, err_stats(got, g["fwd_dual." + name]))
+        assert_close(got, g["fwd_dual." + name], what=name)

@@ -307,3 +307,42 @@ def test_iddpm_oracle_autograd_matches_reference_autograd():
             got = v.grad if v.grad is not None else torch.zeros_like(v)
             scale = float(want.abs().max())
             assert_close(got, want, rtol=1e-4, atol=1e-5 * max(scale, 1e-30), what=f"{tag} grad {k}")
+
+
+def test_oracle_on_config4_steps_with_shipped_church_delta_block():
+    """The oracle against the reference's own config-4 steps (LSUN-church DDPM + the shipped `church_gothic` DeltaBlock,
+    t_edit = 370): the last edited step (384 >= 370) and the first un-edited one."""
+    from conftest import load_golden
+    g = load_golden("config4_church_gothic.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=4004)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    model = sampler.make_model(sd, CELEBA)
+    b = sampler.beta_schedule()
+    one = torch.ones(1)
+    loose = dict(rtol=1e-4, atol=2e-5)
+    x = hash_normal("config4.x384", (1, 3, 256, 256), seed=4004)
+    xn, x0t, dh, _ = sampler.denoising_step(x, one * 384, one * 358, model=model, b=b, eta=0.0, index=0, t_edit=370,
+                                            hs_coeff=(1.0, 1.0))
+    assert_close(dh, g["gen384.delta_h"], what="delta_h", **loose)
+    assert_close(xn, g["gen384.xt_next"], what="xt_next", **loose)
+    x = hash_normal("config4.x358", (1, 3, 256, 256), seed=4004)
+    xn, _, dh, _ = sampler.denoising_step(x, one * 358, one * 333, model=model, b=b, eta=0.0, index=0, t_edit=370,
+                                          hs_coeff=(1.0, 1.0))
+    assert dh is None
+    assert_close(xn, g["gen358.xt_next"], what="xt_next below t_edit", **loose)
+
+
+def test_iddpm_oracle_full_size_imagenet_adm_against_reference():
+    """The oracle's iDDPM family at BASELINE config 5's size against the reference's own i_DDPM('IMAGENET') dual forward."""
+    from conftest import load_golden
+    from oracle.iddpm import IMAGENET, iddpm_forward
+    from test_gpu_iddpm import imagenet_weights
+    g = load_golden("imagenet_adm.npz")
+    sd, x = imagenet_weights()
+    assert torch.equal(x[0, 0, 0, :8], g["probe.x"]) and torch.equal(sd["out.2.weight"].reshape(-1)[:8], g["probe.w"])
+    with torch.no_grad():
+        et, em, dh, mh = iddpm_forward(sd, IMAGENET, x, torch.ones(1) * 700.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    for name, got in (("et", et), ("et_mod", em), ("delta_h", dh), ("middle_h", mh)):
+        assert_close(got, g["fwd_dual." + name], what=name, rtol=1e-4, atol=2e-5)

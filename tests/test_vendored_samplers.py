@@ -1,6 +1,7 @@
 """The vendored sampler signatures: asyrp_official_amd.gaussian_diffusion.GaussianDiffusion against outputs of
 the reference's own models/guided_diffusion/gaussian_diffusion.py (tests/golden/vendored_samplers_small.npz).
-CPU: the wrapper arithmetic with the reference's recorded model output standing in for the UNet.  GPU: the engine-backed UNets."""
+CPU: the host half - the float64 coefficient rows - applied with numpy to the reference's recorded model output.
+GPU: the same through the library's kernel (asyrp_sampler_update), and the engine-backed UNets as the model."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +12,63 @@ from oracle.weights import SMALL, hash_normal
 BETAS = np.linspace(1e-4, 0.02, 1000, dtype=np.float64)
 TIGHT = dict(rtol=1e-5, atol=1e-5)
 CASES = (("ddpm", "small.x", 1, "fixed_large"), ("iddpm", "ismall.x", 2, "learned_range"))
+
+
+def _apply_rows(rows, x, mo, noise=None):
+    """numpy statement of what sampler_update_kernel computes from one coefficient row per image (test-side checker)."""
+    x, mo = x.numpy().astype(np.float64), mo.numpy().astype(np.float64)
+    C = x.shape[1]
+    k = rows.astype(np.float64)[:, :, None, None, None]
+    a, b, p, q, r, lo, hi, clip = (k[:, i] for i in range(8))
+    x0 = a * x - b * mo[:, :C]
+    x0 = np.where(clip != 0, np.clip(x0, -1, 1), x0)
+    out = p * x0 + q * x
+    lv = None
+    if mo.shape[1] == 2 * C:
+        f = (mo[:, C:] + 1) / 2
+        lv = f * hi + (1 - f) * lo
+        r = r * np.exp(0.5 * lv)
+    if noise is not None:
+        out = out + r * noise.numpy().astype(np.float64)
+    return torch.from_numpy(out).float(), torch.from_numpy(x0).float(), (torch.from_numpy(lv).float() if lv is not None else None)
+
+
+def test_coefficient_rows_reproduce_the_reference_on_its_recorded_model_output():
+    from asyrp_official_amd.gaussian_diffusion import SamplerSchedule
+    g = load_golden("vendored_samplers_small.npz")
+    sch = SamplerSchedule(BETAS)
+    for name, xkey, seed, vt in CASES:
+        x = hash_normal(xkey, (2, 3, 32, 32), seed=seed)
+        for tv in (701, 0):
+            t = np.full((2,), tv)
+            mo, pre = g[f"{name}.t{tv}.model_out"], f"{name}.t{tv}"
+            mean, x0, lv = _apply_rows(sch.rows("posterior", t, var_type=vt, clip=True, noisy=False), x, mo)
+            assert_close(mean, g[f"{pre}.pmv.mean"], what=f"{pre} mean", **TIGHT)
+            assert_close(x0, g[f"{pre}.pmv.pred_xstart"], what=f"{pre} pred_xstart", **TIGHT)
+            if vt == "learned_range":
+                assert_close(lv, g[f"{pre}.pmv.log_variance"], what=f"{pre} log_variance", **TIGHT)
+            else:
+                flv = torch.from_numpy(sch.fixed_log_variance(vt, t)).float().view(-1, 1, 1, 1).expand(x.shape)
+                assert_close(flv, g[f"{pre}.pmv.log_variance"], what=f"{pre} log_variance", **TIGHT)
+                assert_close(torch.exp(flv), g[f"{pre}.pmv.variance"], what=f"{pre} variance", **TIGHT)
+            mean, _, _ = _apply_rows(sch.rows("posterior", t, var_type=vt, clip=False, noisy=False), x, mo)
+            assert_close(mean, g[f"{pre}.pmv_noclip.mean"], what=f"{pre} mean (no clip)", **TIGHT)
+            s, _, _ = _apply_rows(sch.rows("posterior", t, var_type=vt, clip=True), x, mo, g[f"{pre}.p_sample.noise"])
+            assert_close(s, g[f"{pre}.p_sample.sample"], what=f"{pre} p_sample", **TIGHT)
+            s, x0, _ = _apply_rows(sch.rows("ddim", t, var_type=vt, clip=False, eta=0.0), x, mo)
+            assert_close(s, g[f"{pre}.ddim.sample"], what=f"{pre} ddim_sample", **TIGHT)
+            assert_close(x0, g[f"{pre}.ddim.pred_xstart"], what=f"{pre} ddim pred_xstart", **TIGHT)
+            s, _, _ = _apply_rows(sch.rows("ddim_reverse", t, var_type=vt, clip=False), x, mo)
+            assert_close(s, g[f"{pre}.ddim_reverse.sample"], what=f"{pre} ddim_reverse_sample", **TIGHT)
+
+
+def test_samplers_have_no_cpu_path():
+    from asyrp_official_amd.engine import AsyrpDeviceError
+    from asyrp_official_amd.gaussian_diffusion import GaussianDiffusion
+    diff = GaussianDiffusion(betas=BETAS)
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(AsyrpDeviceError):
+        diff.ddim_sample(lambda x_, t_: x_, x, torch.zeros(1, dtype=torch.long))
 
 
 def _check(diff, model, x, t, g, pre, dev, tol):
@@ -28,17 +86,30 @@ def _check(diff, model, x, t, g, pre, dev, tol):
     assert_close(rs["sample"], g[f"{pre}.ddim_reverse.sample"], what=f"{pre} ddim_reverse_sample", **tol)
 
 
-def test_wrapper_arithmetic_on_recorded_model_output():
+@pytest.mark.gpu
+def test_kernel_on_recorded_model_output():
     from asyrp_official_amd.gaussian_diffusion import GaussianDiffusion
     g = load_golden("vendored_samplers_small.npz")
     for name, xkey, seed, vt in CASES:
         diff = GaussianDiffusion(betas=BETAS, model_var_type=vt)
-        x = hash_normal(xkey, (2, 3, 32, 32), seed=seed)
+        x = hash_normal(xkey, (2, 3, 32, 32), seed=seed).cuda()
         for tv in (701, 0):
-            t = torch.full((2,), tv, dtype=torch.long)
-            mo = g[f"{name}.t{tv}.model_out"]
+            t = torch.full((2,), tv, dtype=torch.long, device="cuda")
+            mo = g[f"{name}.t{tv}.model_out"].cuda()
             model = lambda x_, t_, **kw: (mo, None, None, None)      # the 4-tuple the Asyrp UNets return
-            _check(diff, model, x, t, g, f"{name}.t{tv}", "cpu", TIGHT)
+            _check(diff, model, x, t, g, f"{name}.t{tv}", "cuda", TIGHT)
+    # denoised_fn sees pred_xstart before the clamp (:299-304)
+    diff = GaussianDiffusion(betas=BETAS, model_var_type="fixed_large")
+    x = hash_normal("small.x", (2, 3, 32, 32), seed=1).cuda()
+    t = torch.full((2,), 701, dtype=torch.long, device="cuda")
+    mo = g["ddpm.t701.model_out"].cuda()
+    model = lambda x_, t_, **kw: (mo, None, None, None)
+    plain = diff.ddim_sample(model, x, t, clip_denoised=True)
+    same = diff.ddim_sample(model, x, t, clip_denoised=True, denoised_fn=lambda v: v)
+    assert_close(same["sample"], plain["sample"].cpu(), what="identity denoised_fn", **TIGHT)
+    half = diff.ddim_sample(model, x, t, clip_denoised=False, denoised_fn=lambda v: 0.5 * v)
+    assert_close(half["pred_xstart"], 0.5 * diff.ddim_sample(model, x, t, clip_denoised=False)["pred_xstart"].cpu(),
+                 what="denoised_fn output is pred_xstart", **TIGHT)
 
 
 @pytest.mark.gpu
