@@ -45,9 +45,9 @@ _SIGS = {
     "asyrp_run_edit": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P]),
     "asyrp_run_inversion": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "asyrp_get_temb": (C.c_int, [_P, _P, _I, _P, _P]),
-    "asyrp_train_forward": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "asyrp_train_backward": (C.c_int, [_P, _P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), _P]),
-    "asyrp_train_discard": (None, [_P]),
+    "asyrp_train_forward": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, C.POINTER(C.c_int64), _P]),
+    "asyrp_train_backward": (C.c_int, [_P, C.c_int64, _P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), _P]),
+    "asyrp_train_discard": (None, [_P, C.c_int64]),
     "asyrp_sampler_update": (C.c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "asyrp_device_bytes": (C.c_int64, [_P]),
     "asyrp_profile_table": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),

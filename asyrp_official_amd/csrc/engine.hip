@@ -132,6 +132,7 @@ struct TapeEntry { int type; int idx; };   // 0 ResnetBlock, 1 AttnBlock, 2 Upsa
 struct Tape {
   bool valid = false;
   int B = 0;
+  int64_t id = 0;                       // generation: asyrp_train_forward stamps it, asyrp_train_backward must present it
   std::vector<TapeEntry> order;
   std::vector<TapeRes> res;
   std::vector<TapeAttn> attn;
@@ -160,6 +161,7 @@ struct asyrp_engine {
   bool has_bound = false;
   hipEvent_t bind_ev = nullptr;
   Tape tape;                            // asyrp_train_forward -> asyrp_train_backward
+  int64_t tape_gen = 0;                 // last generation handed out
   bool bwd_weights = false;             // transposed decoder weight images built (first training call)
 
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
@@ -1209,7 +1211,12 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;
   e->pool.put(temb);
+  // training forward: the pool HOLDS (instead of recycling) exactly what the backward pass reads -- swish(temb), the skip
+  // tensors, the bottleneck h, the timestep projections and everything the DeltaBlock + decoder #2 window returns; the encoder's
+  // and decoder #1's intermediates are recycled as in inference
+  e->pool.defer = (tape != nullptr);
   e->pool.put(temb_act);
+  e->pool.defer = false;
   std::vector<Act> hs;
   Act xin;
   xin.p = const_cast<float*>(x_nhwc); xin.C = cf.in_channels; xin.H = cf.resolution; xin.W = cf.resolution;
@@ -1234,6 +1241,7 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
     if (tape && index != 0) return fail(ASYRP_EINVAL, "the training step supports one DeltaBlock (index 0)");
     c.tape = tape;
+    e->pool.defer = (tape != nullptr);
     for (int i = 0; i <= index; ++i) {
       TRY(deltablock_i(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
       dptr[i] = deltas[i].p;
@@ -1247,13 +1255,16 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     TRY(decoder_i(c, h2, hs, et_mod));
     c.tape = nullptr;
     drop(c, h2);
+    e->pool.defer = false;
   }
   TRY(decoder_i(c, h, hs, et));
   c.skip_share = false;
   for (auto& kv : c.skip_part) drop(c, kv.second);   // (empty unless a pass stopped early)
   c.skip_part.clear();
+  e->pool.defer = (tape != nullptr);                 // skips and timestep projections: read by the backward pass
   for (auto& a : hs) drop(c, a);
   e->pool.put(c.tproj);
+  e->pool.defer = false;
   c.tproj = nullptr;
   return 0;
 }
@@ -1288,7 +1299,12 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;
   e->pool.put(temb);
+  // training forward: the pool HOLDS (instead of recycling) exactly what the backward pass reads -- swish(temb), the skip
+  // tensors, the bottleneck h, the timestep projections and everything the DeltaBlock + decoder #2 window returns; the encoder's
+  // and decoder #1's intermediates are recycled as in inference
+  e->pool.defer = (tape != nullptr);
   e->pool.put(temb_act);
+  e->pool.defer = false;
 
   // encoder (:485-495)
   std::vector<Act> skips;
@@ -1344,6 +1360,7 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     if (index + 1 > 4) return fail(ASYRP_EINVAL, "at most 4 DeltaBlocks can be summed");
     if (tape && index != 0) return fail(ASYRP_EINVAL, "the training step supports one DeltaBlock (index 0)");
     c.tape = tape;
+    e->pool.defer = (tape != nullptr);
     for (int i = 0; i <= index; ++i) {
       TRY(deltablock(c, S("layer_%d", i), h, !ignore_t, &deltas[i]));
       dptr[i] = deltas[i].p;
@@ -1357,13 +1374,16 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     TRY(decoder(c, h2, skips, et_mod));
     c.tape = nullptr;
     drop(c, h2);
+    e->pool.defer = false;
   }
   TRY(decoder(c, h, skips, et));
   c.skip_share = false;
   for (auto& kv : c.skip_part) drop(c, kv.second);   // (empty unless a pass stopped early)
   c.skip_part.clear();
+  e->pool.defer = (tape != nullptr);                 // skips and timestep projections: read by the backward pass
   for (auto& a : skips) drop(c, a);
   e->pool.put(c.tproj);
+  e->pool.defer = false;
   c.tproj = nullptr;
   return 0;
 }
@@ -2011,9 +2031,9 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
 
 int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int B, int learn_sigma,
                         const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* xt_next, float* x0_t,
-                        float* delta_h_out, float* middle_h, void* stream) {
+                        float* delta_h_out, float* middle_h, int64_t* tape_id, void* stream) {
   TRY(check_ready(e, B));
-  if (!xt || !xt_next || !x0_t) return fail(ASYRP_EINVAL, "null tensor");
+  if (!xt || !xt_next || !x0_t || !tape_id) return fail(ASYRP_EINVAL, "null tensor");
   if (e->cfg.n_delta < 1) return fail(ASYRP_EINVAL, "no DeltaBlock (setattr_layers)");
   if (!hs_coeff_host || n_coeff < 2) return fail(ASYRP_EINVAL, "hs_coeff needs 2 entries");
   const asyrp_config& cf = e->cfg;
@@ -2023,15 +2043,14 @@ int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int
   TRY(ensure_bwd_weights(e));
   Ctx c{e, (hipStream_t)stream, B};
   TRY(bind_stream(e, c.s));
-  // a previous tape that was never consumed is discarded
+  // a previous tape that was never consumed is discarded (its id stops being valid)
   e->pool.release_held();
   e->tape.clear();
   struct Guard {   // on any exit: stop deferring; on failure also drop what was held
     asyrp_engine* e; bool ok = false;
     ~Guard() { e->pool.defer = false; if (!ok) { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); } }
   } guard{e};
-  e->pool.defer = true;
-  c.tape = &e->tape;
+  c.tape = &e->tape;        // unet_core holds (pool.defer) what the backward pass reads, and only that
   e->tape.B = B;
   const int HW = cf.resolution * cf.resolution;
   float *xn, *xo, *x0o;
@@ -2047,21 +2066,29 @@ int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int
   HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0_t, B, 3, HW, c.s));
   if (a_dh.p && delta_h_out) HIPCHK(launch_nhwc_to_nchw(a_dh.p, a_dh.C, delta_h_out, B, a_dh.C, a_dh.H * a_dh.W, c.s));
   if (middle_h) HIPCHK(launch_nhwc_to_nchw(a_mid.p, a_mid.C, middle_h, B, a_mid.C, a_mid.H * a_mid.W, c.s));
+  e->pool.defer = false;      // eps, eps~, the DeltaBlock's output and the image buffers are not read by the backward pass
   drop(c, a_et);
   if (a_em.p) drop(c, a_em);
   if (a_dh.p) drop(c, a_dh);
-  drop(c, a_mid);
   e->pool.put(xn); e->pool.put(xo); e->pool.put(x0o);
+  e->pool.defer = true;       // the bottleneck h is (tape.d_h)
+  drop(c, a_mid);
   e->pool.defer = false;
-  e->pool.reclaim();          // (nothing should be live: every buffer was put -> held)
+  e->pool.reclaim();          // (nothing should be live: every buffer was put -> free or held)
   e->tape.valid = true;
+  e->tape.id = ++e->tape_gen;
+  *tape_id = e->tape.id;
   guard.ok = true;
   return 0;
 }
 
-int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, const char* const* keys, float* const* grads,
-                         void* stream) {
-  if (!e || !e->tape.valid) return fail(ASYRP_ESTATE, "asyrp_train_backward without a preceding asyrp_train_forward");
+int asyrp_train_backward(asyrp_engine* e, int64_t tape_id, const float* d_et_mod, int n_grads, const char* const* keys,
+                         float* const* grads, void* stream) {
+  if (!e || !e->finalized) return fail(ASYRP_ESTATE, "asyrp_train_backward on an engine that is not ready");
+  if (!e->tape.valid) return fail(ASYRP_ESTATE, "asyrp_train_backward without a preceding asyrp_train_forward");
+  if (tape_id != e->tape.id)
+    return fail(ASYRP_ESTATE, "asyrp_train_backward: stale tape id (a later asyrp_train_forward replaced the recorded step; the "
+                              "engine keeps ONE pending step)");
   if (!d_et_mod || n_grads < 0 || (n_grads && (!keys || !grads))) return fail(ASYRP_EINVAL, "bad argument");
   Tape& tp = e->tape;
   const int B = tp.B;
@@ -2072,6 +2099,22 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
     asyrp_engine* e;
     ~Guard() { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); }
   } guard{e};
+  {   // every requested key must be a parameter of layer_0 this pass produces a gradient for
+    const bool idd = e->cfg.family == ASYRP_FAMILY_IDDPM;
+    static const char* const kd[] = {"layer_0.conv1.weight", "layer_0.conv1.bias", "layer_0.temb_proj.weight", "layer_0.temb_proj.bias",
+                                     "layer_0.norm2.weight", "layer_0.norm2.bias", "layer_0.conv2.weight", "layer_0.conv2.bias"};
+    static const char* const ki[] = {"layer_0.in_layers.0.weight", "layer_0.in_layers.0.bias", "layer_0.in_layers.2.weight",
+                                     "layer_0.in_layers.2.bias", "layer_0.emb_layers.1.weight", "layer_0.emb_layers.1.bias",
+                                     "layer_0.out_layers.0.weight", "layer_0.out_layers.0.bias", "layer_0.out_layers.3.weight",
+                                     "layer_0.out_layers.3.bias"};
+    for (int i = 0; i < n_grads; ++i) {
+      bool known = false;
+      if (keys[i] && grads[i])
+        for (const char* k : idd ? std::vector<const char*>(ki, ki + 10) : std::vector<const char*>(kd, kd + 8))
+          known = known || !strcmp(k, keys[i]);
+      if (!known) return fail(ASYRP_EKEY, std::string("asyrp_train_backward: no gradient for key ") + (keys[i] ? keys[i] : "(null)"));
+    }
+  }
   auto out_ptr = [&](const std::string& key) -> float* {
     for (int i = 0; i < n_grads; ++i)
       if (key == keys[i]) return grads[i];
@@ -2147,7 +2190,12 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
     HIPCHK(launch_act_bwd_partial(a, c.s));
     float* dgam = out_ptr(K(k_n2, ".weight"));
     float* dbet = out_ptr(K(k_n2, ".bias"));
-    if (dgam && dbet) HIPCHK(launch_gn_param_grad(a.partial, nblk, tp.d_mr, B, Cb, dgam, dbet, c.s));
+    if (dgam || dbet) {   // the kernel writes the pair: an unrequested half goes to scratch
+      float* scratch = nullptr;
+      if (!dgam || !dbet) TRY(e->pool.get((size_t)Cb, &scratch));
+      HIPCHK(launch_gn_param_grad(a.partial, nblk, tp.d_mr, B, Cb, dgam ? dgam : scratch, dbet ? dbet : scratch, c.s));
+      if (scratch) e->pool.put(scratch);
+    }
     GnBwdFinArgs f;
     memset(&f, 0, sizeof f);
     f.partial = a.partial; f.nblk = nblk; f.gamma = P(c, K(k_n2, ".weight")); f.mr = tp.d_mr; f.N = B; f.HW = HWb; f.C = Cb;
@@ -2167,8 +2215,10 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
       // GN0 parameter gradients: dA0 = conv1^T(d_d1), then the partial sums of dA0 * swish'(GN0(h)) against h
       float* dg0 = out_ptr("layer_0.in_layers.0.weight");
       float* db0 = out_ptr("layer_0.in_layers.0.bias");
-      if (dg0 && db0) {
+      if (dg0 || db0) {
         Act dA0, dy0;
+        float* scratch0 = nullptr;
+        if (!dg0 || !db0) TRY(e->pool.get((size_t)Cb, &scratch0));
         TRY(conv_bwd_data(c, d_d1, K(k_c1, ".weight"), Cb, 1, nullptr, &dA0));
         TRY(new_act(c, Cb, tp.d_h.H, tp.d_h.W, &dy0));
         ActBwdArgs a2;
@@ -2177,7 +2227,8 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
         a2.scale = tp.d_sc0; a2.shift = tp.d_sh0; a2.silu = 1; a2.dy = dy0.p; a2.partial = reinterpret_cast<double*>(part);
         a2.HW = HWb; a2.N = B; a2.C = Cb;
         HIPCHK(launch_act_bwd_partial(a2, c.s));
-        HIPCHK(launch_gn_param_grad(a2.partial, nblk, tp.d_mr0, B, Cb, dg0, db0, c.s));
+        HIPCHK(launch_gn_param_grad(a2.partial, nblk, tp.d_mr0, B, Cb, dg0 ? dg0 : scratch0, db0 ? db0 : scratch0, c.s));
+        if (scratch0) e->pool.put(scratch0);
         drop(c, dA0);
         drop(c, dy0);
       }
@@ -2207,8 +2258,9 @@ int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, co
   return 0;
 }
 
-void asyrp_train_discard(asyrp_engine* e) {
-  if (!e) return;
+void asyrp_train_discard(asyrp_engine* e, int64_t tape_id) {
+  if (!e || !e->tape.valid) return;
+  if (tape_id >= 0 && tape_id != e->tape.id) return;   // a newer step replaced it: nothing of `tape_id` is held any more
   e->pool.release_held();
   e->tape.clear();
 }

@@ -222,6 +222,7 @@ class Engine:
 
     # ---- DeltaBlock training step (asyrp_train_forward / asyrp_train_backward) ----------------------
     def train_forward(self, xt, t, t_next, *, hs_coeff=(1.0, 1.0), ignore_timestep=False, learn_sigma=False):
+        """-> (xt_next, x0_t, delta_h, middle_h, tape_id); `tape_id` names the recorded step for train_backward / train_discard."""
         xt = self._image(xt, "xt")
         B = xt.shape[0]
         br, bc = self.bott_res, self.bott_ch
@@ -229,24 +230,35 @@ class Engine:
         dh = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
         mid = torch.empty((B, bc, br, br), device=xt.device, dtype=torch.float32)
         coeff, ncoeff = self._coeff(hs_coeff, 0)
+        tid = C.c_int64(-1)
         with torch.cuda.device(self.device_index):
             _lib.check(self.lib.asyrp_train_forward(self.h, _ptr(xt), int(t), int(t_next), B, int(bool(learn_sigma)), coeff,
                                                     ncoeff, int(bool(ignore_timestep)), _ptr(xn), _ptr(x0t), _ptr(dh),
-                                                    _ptr(mid), self._stream()))
-        return xn, x0t, dh, mid
+                                                    _ptr(mid), C.byref(tid), self._stream()))
+        self._tape_batch = {int(tid.value): B}
+        return xn, x0t, dh, mid, int(tid.value)
 
-    def train_backward(self, d_et_mod, named_shapes):
-        """d_et_mod [B,Cout,R,R]; named_shapes: [(state_dict key, shape)] of the DeltaBlock parameters -> list of gradients."""
+    def train_backward(self, tape_id, d_et_mod, named_shapes):
+        """d_et_mod [B,Cout,R,R] for the step `tape_id`; named_shapes: [(state_dict key, shape)] of DeltaBlock parameters ->
+        list of gradients (zero-initialised device tensors the engine fills)."""
         d = _dev_f32(d_et_mod, "d_et_mod")
-        grads = [torch.empty(tuple(shape), device=d.device, dtype=torch.float32) for _, shape in named_shapes]
+        B = getattr(self, "_tape_batch", {}).get(int(tape_id))
+        if B is not None and tuple(d.shape) != (B, self.out_channels, self.resolution, self.resolution):
+            raise ValueError(f"d_et_mod must be {(B, self.out_channels, self.resolution, self.resolution)} (the recorded step's "
+                             f"eps~), got {tuple(d.shape)}")
+        if d.device.index != self.device_index:
+            raise AsyrpDeviceError(f"d_et_mod lives on {d.device}, the engine on cuda:{self.device_index}")
+        grads = [torch.zeros(tuple(shape), device=d.device, dtype=torch.float32) for _, shape in named_shapes]
         keys = (C.c_char_p * len(grads))(*[k.encode() for k, _ in named_shapes])
         ptrs = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         with torch.cuda.device(self.device_index):
-            _lib.check(self.lib.asyrp_train_backward(self.h, _ptr(d), len(grads), keys, ptrs, self._stream()))
+            _lib.check(self.lib.asyrp_train_backward(self.h, int(tape_id), _ptr(d), len(grads), keys, ptrs, self._stream()))
         return grads
 
-    def train_discard(self):
-        self.lib.asyrp_train_discard(self.h)
+    def train_discard(self, tape_id=-1):
+        """Drop the pending training step `tape_id` (no-op when a later step has replaced it; -1: whatever is pending)."""
+        if self.h:
+            self.lib.asyrp_train_discard(self.h, int(tape_id))
 
     def get_temb(self, t):
         t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")

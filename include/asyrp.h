@@ -174,13 +174,22 @@ int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* 
  *                         convolutions on the same MFMA kernels; GroupNorm / SiLU / attention / upsample backward) to the
  *                         bottleneck and writes the gradients of the named DeltaBlock parameters ("layer_0.conv1.weight",
  *                         ... reference state_dict names and shapes) to the given DEVICE buffers.  Consumes the tape.
- *   asyrp_train_discard   drops an unconsumed tape (e.g. a step whose loss is not back-propagated). */
+ *   asyrp_train_discard   drops an unconsumed tape (e.g. a step whose loss is not back-propagated).
+ * The engine keeps ONE pending step.  asyrp_train_forward stamps it with a generation id (*tape_id); asyrp_train_backward must
+ * present that id and fails with ASYRP_ESTATE when a later forward has replaced the step (forward A, forward B, backward(A)
+ * would otherwise back-propagate B's activations); asyrp_train_discard(e, id) is a no-op for a stale id (id < 0: whatever is
+ * pending).  Until the backward or a discard, the engine holds the tensors the backward reads (the skip tensors, the bottleneck,
+ * decoder #2's and the DeltaBlock's activations) out of its workspace pool; the encoder's and decoder #1's intermediates are
+ * recycled as in inference.  Every key handed to asyrp_train_backward must name a layer_0 parameter (ASYRP_EKEY otherwise).
+ * Numerics note: the training forward evaluates decoder #2 without the skip-half sharing of the inference step and its attention
+ * in the three-launch fp32-MFMA form (it keeps the softmax probabilities), so x0_t of asyrp_train_forward and of
+ * asyrp_ddim_step on the same inputs agree to rounding (tested at rtol 1e-3 / atol 1e-4 x 1/sqrt(alpha_bar_t)), not bitwise. */
 int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int B, int learn_sigma,
                         const float* hs_coeff_host, int n_coeff, int ignore_timestep, float* xt_next, float* x0_t,
-                        float* delta_h_out, float* middle_h, void* stream);
-int asyrp_train_backward(asyrp_engine* e, const float* d_et_mod, int n_grads, const char* const* keys, float* const* grads_dev,
-                         void* stream);
-void asyrp_train_discard(asyrp_engine* e);
+                        float* delta_h_out, float* middle_h, int64_t* tape_id, void* stream);
+int asyrp_train_backward(asyrp_engine* e, int64_t tape_id, const float* d_et_mod, int n_grads, const char* const* keys,
+                         float* const* grads_dev, void* stream);
+void asyrp_train_discard(asyrp_engine* e, int64_t tape_id);
 
 /* DDPM.get_temb (models/ddpm/diffusion.py:464-470): t [B] float timesteps (device) -> temb [B, 4*ch] (device).
  * For the iDDPM family: time_embed(timestep_embedding(t)) (models/improved_ddpm/unet.py:688). */
