@@ -59,12 +59,27 @@ _SIGS = {
                                   _P, _I, _I, _P]),
     "asyrp_op_conv2d_stats": (C.c_int, [_I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     "asyrp_op_resblock_tail": (C.c_int, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P, _P]),
-    "asyrp_op_conv_bench": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P]),
     "asyrp_op_attention": (C.c_int, [_I, _P, _I, _I, _I, _I, _I, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
+# the profiling library (same sources + -DASYRP_BENCH_HOOKS): scripts/conv_bench.py only, never loaded by the package
+BENCH_LIB_PATH = os.path.join(_HERE, "libasyrp_hip_bench.so")
+BENCH_SIGS = {"asyrp_op_conv_bench": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P])}
+
 _lib = None
+
+
+def load_bench():
+    """The profiling build (python -m asyrp_official_amd.build --bench): every product symbol + asyrp_op_conv_bench."""
+    if not os.path.exists(BENCH_LIB_PATH):
+        raise RuntimeError(f"{BENCH_LIB_PATH} not found: build it with `python -m asyrp_official_amd.build --bench`")
+    lib = C.CDLL(BENCH_LIB_PATH)
+    for name, (res, args) in {**_SIGS, **BENCH_SIGS}.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():

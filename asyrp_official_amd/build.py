@@ -6,7 +6,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libasyrp_hip.so")
+LIB = PRODUCT_LIB = os.path.join(HERE, "libasyrp_hip.so")
+BENCH_LIB = os.path.join(HERE, "libasyrp_hip_bench.so")
 SOURCES = ["kernels.hip", "conv_f16x3.hip", "conv_out.hip", "attention.hip", "backward.hip", "engine.hip"]
 DEPS = SOURCES + ["kernels.h", os.path.join("..", "..", "include", "asyrp.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-comment"]
@@ -19,23 +20,26 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=PRODUCT_LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, bench_hooks=False):
     """Compile the HIP sources into asyrp_official_amd/libasyrp_hip.so; returns the path.
-    One hipcc -c per source, run concurrently (objects under csrc/build/, git-ignored), then one link."""
-    if not force and not needs_build():
+    One hipcc -c per source, run concurrently (objects under csrc/build/, git-ignored), then one link.
+    bench_hooks: the profiling library libasyrp_hip_bench.so instead (same sources with -DASYRP_BENCH_HOOKS: adds
+    asyrp_op_conv_bench and the ablation instantiations of the main tile; used by scripts/conv_bench.py only)."""
+    LIB = BENCH_LIB if bench_hooks else PRODUCT_LIB
+    if not force and not needs_build(LIB):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build", "bench" if bench_hooks else "")
     os.makedirs(objdir, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"]
+    cflags = [f for f in FLAGS if f != "-shared"] + (["-DASYRP_BENCH_HOOKS"] if bench_hooks else [])
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, d)) for d in DEPS if not d.endswith(".hip"))
 
     def compile_one(src):
@@ -60,5 +64,4 @@ def build_library(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB)
+    print(build_library(force="--force" in sys.argv, bench_hooks="--bench" in sys.argv))

@@ -111,8 +111,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 
 // VEC: Cin, c0, c1 and both row strides are multiples of 16 floats and the bases 16-B aligned (every layer but
 // conv_in): a K-chunk is 16 contiguous floats of ONE source per pixel -> two global_load_dwordx4 per work item.
-// ABL: profiling-only instantiation whose phases can be switched off at run time through p.abl (timing ablations;
-//      results are then wrong by construction): 1 = no staging math, 2 = no weight LDS-DMA in the loop, 4 = no MFMA,
+// ABL: profiling-only instantiation (compiled with -DASYRP_BENCH_HOOKS into libasyrp_hip_bench.so only) whose phases can be
+//      switched off at run time through p.abl (timing ablations; results are then wrong by construction): 1 = no staging math, 2 = no weight LDS-DMA in the loop, 4 = no MFMA,
 //      8 = no activation loads/writes in the loop, 16 = no per-step wait+barrier.
 // PIPE: software-pipelined K-loop (4-wave tiles): the per-step barrier sits between MFMA pass 2 and pass 3, the next
 //       step's x_lo / w_hi fragments are fetched right after it and their LDS latency is covered by pass 3, so every
@@ -773,8 +773,9 @@ struct K32Cfg {
 //     needs BOTH its 16-channel chunks in LDS at once, so the shortcut phase turns the two halo buffers into ONE centre-only tile
 //     of 32 channels ([8 units][BM pixels][16 B], 32 KB on the main tile): raw loads for the next step travel in registers under the matrix
 //     passes, the split + LDS write sits between two barriers (Cin2 % 32 == 0).
-// ABL: profiling-only instantiation (scripts/conv_bench.py): p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the
-//      loop, 4 = no matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
+// ABL: profiling-only instantiation, compiled with -DASYRP_BENCH_HOOKS into libasyrp_hip_bench.so for scripts/conv_bench.py
+//      and absent from the product library: p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the loop, 4 = no
+//      matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
 template <class T, bool SC, bool ABL = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
@@ -1303,10 +1304,12 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
     if (a.ks == 3) return big ? launch_x<X256x128_3plain, false>(a, s) : launch_x<X64x128_3plain, false>(a, s);
     return big ? launch_x<X256x128_1plain, false>(a, s) : launch_x<X64x128_1plain, false>(a, s);
   }
-  if (a.abl) {   // profiling build of the main tile only
+  if (a.abl) {   // timing ablations of the main tile: instantiated in the profiling library only (libasyrp_hip_bench.so)
+#ifdef ASYRP_BENCH_HOOKS
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true>(a, s);
     if (a.ks == 3 && a.stride == 1 && a.tile == XT_256x128K32 && !a.s0 && (a.Cin & 31) == 0) return launch_k32<K32Main, false, true>(a, s);
     if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true>(a, s);
+#endif
     return hipErrorInvalidValue;
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)

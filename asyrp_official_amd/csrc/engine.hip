@@ -2641,6 +2641,7 @@ __global__ void fill_hash_kernel(float* p, long long n, unsigned seed, float sca
   }
 }
 
+#ifdef ASYRP_BENCH_HOOKS   // the profiling library only (libasyrp_hip_bench.so, scripts/conv_bench.py)
 int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
                         void* stream) {
@@ -2722,6 +2723,7 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   *ms_out = ms / iters;
   return 0;
 }
+#endif
 
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream) {
   if (!qkv || !out || B < 1 || heads < 1 || C % heads) return fail(ASYRP_EINVAL, "bad argument");

@@ -320,7 +320,15 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)",
                        "launcher": "self (bench.py re-executed under torch.distributed.run)"
                        if os.environ.get("ASYRP_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
-                       "collective_backend": (backend if world > 1 else None)},
+                       "collective_backend": (backend if world > 1 else None),
+                       # proof that the collective library saw N ranks (a SCALE record is judged on this)
+                       "world_size": world,
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                        if world > 1 and backend == "nccl" else None),
+                       # A/B switches read by the library from the environment: a non-default kernel choice can never be
+                       # benchmarked silently
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP")},
+                       "conv_math": a.conv_math},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
             "generation_only_images_per_s": B * world / (1e-3 * (20 * phases["generation_step_t>=t_edit(dual decoder)"] +

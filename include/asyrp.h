@@ -260,17 +260,23 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
 int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, int C0, const float* x1, int C1, int B, int H,
                            int W, const float* w3, const float* b3, const float* w1, const float* b1, int Cout,
                            const float* gn_weight, const float* gn_bias, float gn_eps, float* y, void* stream);
-/* Kernel micro-benchmark (scripts/conv_bench.py): times `iters` launches of one conv configuration on synthetic
- * NHWC buffers with HIP events and returns the average in *ms_out (host pointer).  `abl` != 0 selects the profiling
- * build of the main f16x3 tile with phases switched off (timing ablations only). */
-int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
-                        int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
-                        void* stream);
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
  * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T].
  * fused != 0: the one-launch f16x3 kernel (csrc/attention.hip; T <= 1024, head width <= 512, multiple of 16), the engine's
  * default; fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream);
+
+#ifdef ASYRP_BENCH_HOOKS
+/* ---- profiling library only: libasyrp_hip_bench.so = the same sources compiled with -DASYRP_BENCH_HOOKS ---------------
+ * (python -m asyrp_official_amd.build --bench).  The product library neither exports this entry point nor contains the
+ * ablation instantiations of the kernels.
+ * Kernel micro-benchmark (scripts/conv_bench.py): times `iters` launches of one conv configuration on synthetic
+ * NHWC buffers with HIP events and returns the average in *ms_out (host pointer).  `abl` != 0 selects the ablation
+ * build of the main f16x3 tile with phases switched off (timing only; results are then wrong by construction). */
+int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                        int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                        void* stream);
+#endif
 
 #ifdef __cplusplus
 }

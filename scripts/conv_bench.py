@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 from asyrp_official_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_bench()      # libasyrp_hip_bench.so (python -m asyrp_official_amd.build --bench): product kernels + bench hooks
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 
 

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_multi.py: launched by torch.distributed.run, one process per GPU, RCCL (backend "nccl").
-Every rank edits its batch shard with no data-path collective; one all-gather of x_edit; rank 0 compares with the
-unsharded run on its own GPU (bitwise) and prints OK."""
+Every rank edits its batch shard with no data-path collective; one all-gather of x_edit; every rank compares the
+gathered batch with the unsharded run on its own GPU (bitwise); rank 0 prints OK with the RCCL version."""
 import os
 import sys
 
@@ -28,10 +28,15 @@ def main():
     kw = dict(n_inv=4, n_gen=4, t_edit=500)
     full = run_edit_sharded(m, x, b, **kw)
     assert full.shape == x.shape
+    # EVERY rank holds the full batch after the one all-gather, and it equals the unsharded edit on that rank's own GPU bit for
+    # bit (batch-invariant kernels: sharding cannot change an image)
+    alone = run_edit(m, x, b, **kw)
+    same = torch.tensor([int(torch.equal(full, alone))], device="cuda")
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    assert int(same.item()) == 1, "sharded + all-gathered result differs from the unsharded one on some rank"
     if rank == 0:
-        alone = run_edit(m, x, b, **kw)
-        assert torch.equal(full, alone), "sharded + all-gathered result differs from the unsharded one"
-        print(f"MULTI_GPU_OK world={world} backend={dist.get_backend()}", flush=True)
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        print(f"MULTI_GPU_OK world={world} backend={dist.get_backend()} rccl={ver}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

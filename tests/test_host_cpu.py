@@ -17,10 +17,14 @@ from util_models import namespace_for
 REF = os.environ.get("ASYRP_REFERENCE", "/root/reference")
 
 
-def _header_functions():
+def _header_functions(bench_hooks=False):
+    """Entry points include/asyrp.h declares for the product library (or, bench_hooks: only those inside #ifdef ASYRP_BENCH_HOOKS)."""
     src = open(os.path.join(ROOT, "include", "asyrp.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(asyrp_[a-z0-9_]+)\s*\(", src)))
+    hooks = "".join(re.findall(r"#ifdef ASYRP_BENCH_HOOKS(.*?)#endif", src, flags=re.S))
+    if not bench_hooks:
+        src = re.sub(r"#ifdef ASYRP_BENCH_HOOKS.*?#endif", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asyrp_[a-z0-9_]+)\s*\(", hooks if bench_hooks else src)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -33,6 +37,11 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes signature table and include/asyrp.h disagree"
     header = open(os.path.join(ROOT, "include", "asyrp.h")).read()
     assert lib.asyrp_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define ASYRP_ABI_VERSION (\d+)", header).group(1))
+    # the profiling hooks are NOT in the product library (they live in libasyrp_hip_bench.so, built with -DASYRP_BENCH_HOOKS)
+    hooks = _header_functions(bench_hooks=True)
+    assert hooks == sorted(_lib.BENCH_SIGS) and hooks
+    for name in hooks:
+        assert not hasattr(lib, name), f"profiling hook {name} leaked into the product library"
 
 
 def test_engine_parameter_inventory_equals_reference_state_dict():
