@@ -43,7 +43,9 @@ class HipUNet(nn.Module):
 
     def _init_params(self, max_batch, conv_math):
         self.max_batch = int(max_batch)
-        self.conv_math = conv_math      # "f16x3" (3 x f16 MFMA, fp32-equivalent, default) or "f32" (fp32 MFMA)
+        # "f16x3" (3 x f16 MFMA, fp32-equivalent, default), "f32" (fp32 MFMA), or the fast mode "f16" (ONE f16 MFMA per product:
+        # not fp32-equivalent, reported separately with its own error; include/asyrp.h enum asyrp_conv_math)
+        self.conv_math = conv_math
         self._n_delta = 0
         self._engine = None
         self._engine_sig = None

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libasyrp_hip.so")
 
 MAX_LEVELS = 8
 FAMILY_DDPM, FAMILY_IDDPM = 0, 1
-MATH_F16X3, MATH_F32 = 0, 1
-CONV_MATH = {"f16x3": MATH_F16X3, "f32": MATH_F32}
+MATH_F16X3, MATH_F32, MATH_F16 = 0, 1, 2
+CONV_MATH = {"f16x3": MATH_F16X3, "f32": MATH_F32, "f16": MATH_F16}   # f16 = the single-product fast mode (not fp32-equivalent)
 
 
 class AsyrpConfig(C.Structure):

@@ -48,7 +48,8 @@ __device__ __forceinline__ void asplit8(const float (&v)[8], h8& hi, h8& lo) {
 }
 
 // NKT = 32-key tiles per wave (T <= NKT*128); DCH = 32-channel output tiles accumulated per pass over the keys
-template <int NKT, int DCH>
+// NP = matrix products per term: 3 (two-term split, fp32-equivalent) or 1 (conv_math "f16": hi terms only)
+template <int NKT, int DCH, int NP = 3>
 __global__ void __launch_bounds__(256, 1) attn_f16x3_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -114,9 +115,9 @@ __global__ void __launch_bounds__(256, 1) attn_f16x3_kernel(const AttnArgs p) {
                             kb[buf][kt].x, kb[buf][kt].y, kb[buf][kt].z, kb[buf][kt].w};
         h8 khi, klo;
         asplit8(v, khi, klo);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qh, s[kt], 0, 0, 0);
+        if (NP == 3) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qh, s[kt], 0, 0, 0);
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qh, s[kt], 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, ql, s[kt], 0, 0, 0);
+        if (NP == 3) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, ql, s[kt], 0, 0, 0);
       }
     };
 #pragma unroll
@@ -219,9 +220,9 @@ __global__ void __launch_bounds__(256, 1) attn_f16x3_kernel(const AttnArgs p) {
           for (int j = 0; j < 8; ++j) v[j] = dok[dt] ? vb[st % RV][dt][j] : 0.f;
           h8 vhi, vlo;
           asplit8(v, vhi, vlo);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(plo[kt][k2], vhi, o[dt], 0, 0, 0);
+          if (NP == 3) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(plo[kt][k2], vhi, o[dt], 0, 0, 0);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[kt][k2], vhi, o[dt], 0, 0, 0);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[kt][k2], vlo, o[dt], 0, 0, 0);
+          if (NP == 3) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(phi[kt][k2], vlo, o[dt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -246,23 +247,27 @@ __global__ void __launch_bounds__(256, 1) attn_f16x3_kernel(const AttnArgs p) {
   }
 }
 
-template <int NKT, int DCH>
-static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+template <int NKT, int DCH, int NP>
+static hipError_t launch_attn_np(const AttnArgs& a, hipStream_t s) {
   const size_t smem = (size_t)(a.Dh >> 4) * 4 * 32 * 16 + 2 * 4 * 32 * sizeof(float) + (size_t)4 * 32 * DCH * 32 * sizeof(float);
   static bool attr_set[16] = {};
   if (smem > 64 * 1024) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<NKT, DCH>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<NKT, DCH, NP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
   }
   dim3 grid((a.T + 31) / 32, a.heads, a.B);
-  hipLaunchKernelGGL((attn_f16x3_kernel<NKT, DCH>), grid, dim3(256), smem, s, a);
+  hipLaunchKernelGGL((attn_f16x3_kernel<NKT, DCH, NP>), grid, dim3(256), smem, s, a);
   return hipGetLastError();
+}
+template <int NKT, int DCH>
+static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+  return a.np == 1 ? launch_attn_np<NKT, DCH, 1>(a, s) : launch_attn_np<NKT, DCH, 3>(a, s);
 }
 
 bool attn_fused_supported(int T, int Dh, int ld, int ldo) {

@@ -109,6 +109,20 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
   }
 }
 
+// single-product mode: 8 fp32 values -> f16 (round to nearest even, |x| clamped to the f16 range)
+__device__ __forceinline__ h8 round8(const float (&v)[8]) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 s;
+    s[0] = __builtin_amdgcn_fmed3f(v[j] * ACT_SCALE, -H_MAX, H_MAX);
+    s[1] = __builtin_amdgcn_fmed3f(v[j + 1] * ACT_SCALE, -H_MAX, H_MAX);
+    const h2 h = __builtin_convertvector(s, h2);
+    r[j] = h[0]; r[j + 1] = h[1];
+  }
+  return r;
+}
+
 // VEC: Cin, c0, c1 and both row strides are multiples of 16 floats and the bases 16-B aligned (every layer but
 // conv_in): a K-chunk is 16 contiguous floats of ONE source per pixel -> two global_load_dwordx4 per work item.
 // ABL: profiling-only instantiation (compiled with -DASYRP_BENCH_HOOKS into libasyrp_hip_bench.so only) whose phases can be
@@ -119,7 +133,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 //       step opens with matrix work already fed from registers.  Same products in the same order as the plain loop.
 // SC:   fused 1x1 shortcut: Cin2/16 extra single-tap K-chunks over the raw tensor (s0|s1) after the 3x3 chunks (TS=1);
 //       launched on the 8-wave tile (plain loop); the pipelined loop keeps its implementation for A/B
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
+// NP:   matrix products per term: 3 = two-term split (fp32-equivalent), 1 = single f16 product (conv_math "f16": only the hi
+//       planes are staged and multiplied; the weight slices are still DMA'd whole -- these tiles are not the dominant ones)
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, int NP = 3>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int WN = T::WN, TM = T::TM, TN = T::TN, KS = T::KS, STRIDE = T::STRIDE, NW = T::NW;
@@ -287,12 +303,16 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
           for (int j = 0; j < 8; ++j) t[j] = (c + j < Cin) ? t[j] : 0.f;
         }
       }
-      h8 hi, lo;
-      split8(t, hi, lo);
       const int pix = (tid + i * NT) >> 1;
       char* dst = As + buf * A_BYTES + (hf * NPIX + pix) * 16;
-      *reinterpret_cast<h8*>(dst) = hi;
-      *reinterpret_cast<h8*>(dst + 2 * NPIX * 16) = lo;
+      if (NP == 1) {
+        *reinterpret_cast<h8*>(dst) = round8(t);
+      } else {
+        h8 hi, lo;
+        split8(t, hi, lo);
+        *reinterpret_cast<h8*>(dst) = hi;
+        *reinterpret_cast<h8*>(dst + 2 * NPIX * 16) = lo;
+      }
     }
   };
 
@@ -342,6 +362,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   if (PIPE) {
     constexpr int RB = T::RB, NPW = T::NPW, TS = T::TS;
     constexpr int SLOT_BYTES = TS * B_BYTES;
+    // plane of the A fragments fetched one step ahead ("al"): x_lo of the three-product scheme, x_hi itself when NP == 1
+    constexpr int A_PRE = (NP == 1) ? 0 : 2 * NPIX * 16;
     static_assert((TS * T::NPIECE) % NW == 0 || RB == 2,
                   "a ring deeper than 2 counts LDS-DMA instructions per wave: every wave must issue the same number per slot");
     static_assert(NTAPS % TS == 0, "a fat step must not straddle two channel chunks");
@@ -387,7 +409,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       const char* A = As + (cb & 1) * A_BYTES + kh * NPIX * 16;
       const char* B = Bs + boff;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);
+      for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + A_PRE);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
     }
@@ -405,20 +427,24 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       // the first MFMA (pinned: the compiler's lgkmcnt wait for al/bh must not sit behind freshly issued reads)
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (NP == 3) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
+        for (int tm = 0; tm < TM; ++tm) ah[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
+        for (int tn = 0; tn < TN; ++tn) bl[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16 + 2 * BN * 16);
+      }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           if (tm + tn > 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      if (NP == 3) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
       int nchunk = chunk, ntap = tap + 1;
       if (ntap == ntaps_c) { ntap = 0; ++nchunk; }
       int nslot = slot, ntt = tt + 1;
@@ -452,15 +478,17 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         const char* An = As + (nchunk & 1) * A_BYTES + (kh * NPIX + nky * TW + nkx) * 16;
         const char* Bn = Bs + nslot * SLOT_BYTES + ntt * B_BYTES + boff;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(An + apix[tm] * 16 + 2 * NPIX * 16);
+        for (int tm = 0; tm < TM; ++tm) al[tm] = *reinterpret_cast<const h8*>(An + apix[tm] * 16 + A_PRE);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const h8*>(Bn + tn * 32 * 16);
       }
+      if (NP == 3) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+      }
       tap = ntap;
       chunk = nchunk;
       if (endfat) ++fs;
@@ -497,7 +525,18 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
         const char* A = As + (chunk & 1) * A_BYTES + (kh * NPIX + ky * TW + kx) * 16;
         const char* B = Bs + (step & 1) * B_BYTES + boff;
         // pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) is the same in every variant: results are bit-identical across tiles
-        if (LOWREG) {
+        if (NP == 1) {   // single product x_hi * w_hi
+          h8 fa[TM], fb[TN];
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16);
+  #pragma unroll
+          for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 32 * 16);
+  #pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        } else if (LOWREG) {
           h8 fa[TM], fb[TN];
   #pragma unroll
           for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + apix[tm] * 16 + 2 * NPIX * 16);   // x_lo
@@ -776,7 +815,10 @@ struct K32Cfg {
 // ABL: profiling-only instantiation, compiled with -DASYRP_BENCH_HOOKS into libasyrp_hip_bench.so for scripts/conv_bench.py
 //      and absent from the product library: p.abl switches phases off at run time -- 2 = no weight LDS-DMA in the loop, 4 = no
 //      matrix instructions (fragment reads kept), 8 = no activation loads / staging in the loop (results are then wrong)
-template <class T, bool SC, bool ABL = false>
+// NP:  matrix products per term.  3 = the fp32-equivalent two-term split (x_lo*w_hi + x_hi*w_hi + x_hi*w_lo); 1 = the single-
+//      product f16 mode (conv_math "f16": x_hi*w_hi only, fp32 accumulate): the lo planes are neither computed, staged,
+//      DMA'd nor read -- one third of the matrix work, half the weight bytes, a lighter staging pass.
+template <class T, bool SC, bool ABL = false, int NP = 3>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE, WN = T::WN, WM = T::WM, TN = T::TN, BM = T::BM;
@@ -867,19 +909,26 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
           for (int j = 0; j < 8; ++j) t[j] = silu_fast(t[j]);
         }
       }
-      h8 hi, lo;
-      split8(t, hi, lo);
       const int pix = (tid + i * NT) >> 1;
       char* dst = As + buf * A_BYTES + (hf * PLANE + pix) * 16;
-      *reinterpret_cast<h8*>(dst) = hi;
-      *reinterpret_cast<h8*>(dst + 2 * PLANE * 16) = lo;
+      if (NP == 1) {
+        *reinterpret_cast<h8*>(dst) = round8(t);
+      } else {
+        h8 hi, lo;
+        split8(t, hi, lo);
+        *reinterpret_cast<h8*>(dst) = hi;
+        *reinterpret_cast<h8*>(dst + 2 * PLANE * 16) = lo;
+      }
     }
   };
   // the two weight slices of K-step s are consecutive in the packed image: 16 1-KiB LDS-DMA pieces, 16 / NW per wave
+  // (NP == 1: only the 8 pieces of the hi units, one per wave)
   auto issue_slot = [&](int s, int slot) {
 #pragma unroll
-    for (int k = 0; k < T::NPW; ++k) {
-      const int pc = wave + k * T::NW, i = pc >> 3, u = (pc & 7) >> 1, part = pc & 1;
+    for (int k = 0; k < (NP == 1 ? (8 + T::NW - 1) / T::NW : T::NPW); ++k) {
+      const int pc = wave + k * T::NW;
+      if (NP == 1 && T::NW > 8 && pc >= 8) break;
+      const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
       const char* src = wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
       char* dst = Bs + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -922,6 +971,17 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i % TN]));
       }
+      return;
+    }
+    if (NP == 1) {   // single product: x_hi * w_hi
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const h8*>(A + tm * a_tm);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fb[tn] = *reinterpret_cast<const h8*>(B + tn * 256);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
       return;
     }
 #pragma unroll
@@ -973,13 +1033,17 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     for (int i = 0; i < NSC; ++i) {
       const float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                           areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
-      h8 hi, lo;
-      split8(t, hi, lo);
       const int pix = (tid + i * NT) >> 2;
       if (pix >= BM) continue;
       char* dst = As + (q * BM + pix) * 16;
-      *reinterpret_cast<h8*>(dst) = hi;
-      *reinterpret_cast<h8*>(dst + 4 * BM * 16) = lo;
+      if (NP == 1) {
+        *reinterpret_cast<h8*>(dst) = round8(t);
+      } else {
+        h8 hi, lo;
+        split8(t, hi, lo);
+        *reinterpret_cast<h8*>(dst) = hi;
+        *reinterpret_cast<h8*>(dst + 4 * BM * 16) = lo;
+      }
     }
   };
 
@@ -1111,7 +1175,7 @@ static bool xcd_map_enabled() {
   return on;
 }
 
-template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false>
+template <class T, bool VEC, bool ABL = false, bool PIPE = false, bool SC = false, int NP = 3>
 static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   int gx;
   if (T::KS == 1) {
@@ -1135,13 +1199,13 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, NP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC>), grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL((igemm_f16x3_kernel<T, VEC, ABL, PIPE, SC, NP>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
@@ -1149,7 +1213,7 @@ using K32Main = K32Cfg<8, 2>;
 using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
-template <class T, bool SC, bool ABL = false>
+template <class T, bool SC, bool ABL = false, int NP = 3>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
   const int gy = (a.Cout + T::BN - 1) / T::BN;
@@ -1160,12 +1224,12 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (T::SMEM > 64 * 1024 && (dev < 0 || dev >= 16 || !attr_set[dev])) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<T, SC, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<T, SC, ABL, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<T, SC, ABL>), grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<T, SC, ABL, NP>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
@@ -1271,7 +1335,8 @@ int gemm_mblocks(const GemmArgs& a) {
   return ((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
 }
 
-hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
+template <int NP>
+static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
   if (!a.wpk || a.bT || a.ZI > 1 || a.cout_pad < ((a.Cout + 127) / 128) * 128) return hipErrorInvalidValue;
   if (!(a.ks == 1 || a.ks == 3) || !(a.stride == 1 || a.stride == 2)) return hipErrorInvalidValue;
   if (a.ks == 1 && (a.stride != 1 || a.ups)) return hipErrorInvalidValue;
@@ -1299,50 +1364,58 @@ hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
   using X256x128_1plain = XCfg<4, 1, 2, 4, 1, 1>;
   using X64x128_1plain = XCfg<2, 2, 1, 2, 1, 1>;
   if (!is_vec(a)) {   // ragged channel counts (conv_in: Cin = 3): scalar-gather staging, two tile shapes per kernel size
-    if (a.stride == 2) return launch_x<X64x128_3s2plain, false>(a, s);
+    if (a.stride == 2) return launch_x<X64x128_3s2plain, false, false, false, false, NP>(a, s);
     const bool big = (tile == XT_256x128);
-    if (a.ks == 3) return big ? launch_x<X256x128_3plain, false>(a, s) : launch_x<X64x128_3plain, false>(a, s);
-    return big ? launch_x<X256x128_1plain, false>(a, s) : launch_x<X64x128_1plain, false>(a, s);
+    if (a.ks == 3) return big ? launch_x<X256x128_3plain, false, false, false, false, NP>(a, s) : launch_x<X64x128_3plain, false, false, false, false, NP>(a, s);
+    return big ? launch_x<X256x128_1plain, false, false, false, false, NP>(a, s) : launch_x<X64x128_1plain, false, false, false, false, NP>(a, s);
   }
+  if (a.abl && NP != 3) return hipErrorInvalidValue;
   if (a.abl) {   // timing ablations of the main tile: instantiated in the profiling library only (libasyrp_hip_bench.so)
 #ifdef ASYRP_BENCH_HOOKS
-    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128) return launch_x<X256x128_3plain, true, true, false, false>(a, s);
     if (a.ks == 3 && a.stride == 1 && a.tile == XT_256x128K32 && !a.s0 && (a.Cin & 31) == 0) return launch_k32<K32Main, false, true>(a, s);
-    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true>(a, s);
+    if (a.ks == 3 && a.stride == 1 && tile == XT_256x128W8) return launch_x<XCfg<4, 2, 2, 2, 3, 1>, true, true, false, false>(a, s);
 #endif
     return hipErrorInvalidValue;
   }
   if (a.s0) {   // fused 1x1 shortcut: main tile only (gemm_can_fuse_shortcut)
     if (!gemm_can_fuse_shortcut(a)) return hipErrorInvalidValue;
-    if (tile == XT_256x128K32) return launch_k32<K32Main, true>(a, s);
-    if (tile == XT_128x128K32) return launch_k32<K32Half, true>(a, s);
-    if (tile == XT_64x128K32) return launch_k32<K32Img8, true>(a, s);
-    return launch_x<X256x128w8_3, true, false, false, true>(a, s);
+    if (tile == XT_256x128K32) return launch_k32<K32Main, true, false, NP>(a, s);
+    if (tile == XT_128x128K32) return launch_k32<K32Half, true, false, NP>(a, s);
+    if (tile == XT_64x128K32) return launch_k32<K32Img8, true, false, NP>(a, s);
+    return launch_x<X256x128w8_3, true, false, false, true, NP>(a, s);
   }
   if (a.ks == 3) {
-    if (a.stride == 2) return tile == XT_64x128K32S2 ? launch_k32<K32S2, false>(a, s) : launch_x<X64x128_3s2, true, false, true>(a, s);
+    if (a.stride == 2) return tile == XT_64x128K32S2 ? launch_k32<K32S2, false, false, NP>(a, s) : launch_x<X64x128_3s2, true, false, true, false, NP>(a, s);
     switch (tile) {
-      case XT_256x128: return launch_x<X256x128_3, true, false, true>(a, s);
-      case XT_128x128: return launch_x<X128x128_3, true, false, true>(a, s);
-      case XT_64x128: return launch_x<X64x128_3, true, false, true>(a, s);
-      case XT_64x64: return launch_x<X64x64_3, true, false, true>(a, s);
-      case XT_256x64: return launch_x<X256x64_3, true, false, true>(a, s);
-      case XT_256x32: return launch_x<X256x32_3, true, false, true>(a, s);
-      case XT_256x128W8: return launch_x<X256x128w8_3, true>(a, s);
-      case XT_256x128K32: return launch_k32<K32Main, false>(a, s);
-      case XT_128x128K32: return launch_k32<K32Half, false>(a, s);
-      case XT_64x128K32: return launch_k32<K32Img8, false>(a, s);
+      case XT_256x128: return launch_x<X256x128_3, true, false, true, false, NP>(a, s);
+      case XT_128x128: return launch_x<X128x128_3, true, false, true, false, NP>(a, s);
+      case XT_64x128: return launch_x<X64x128_3, true, false, true, false, NP>(a, s);
+      case XT_64x64: return launch_x<X64x64_3, true, false, true, false, NP>(a, s);
+      case XT_256x64: return launch_x<X256x64_3, true, false, true, false, NP>(a, s);
+      case XT_256x32: return launch_x<X256x32_3, true, false, true, false, NP>(a, s);
+      case XT_256x128W8: return launch_x<X256x128w8_3, true, false, false, false, NP>(a, s);
+      case XT_256x128K32: return launch_k32<K32Main, false, false, NP>(a, s);
+      case XT_128x128K32: return launch_k32<K32Half, false, false, NP>(a, s);
+      case XT_64x128K32: return launch_k32<K32Img8, false, false, NP>(a, s);
     }
   } else {
     switch (tile) {
-      case XT_256x128: return launch_x<X256x128_1, true, false, true>(a, s);
-      case XT_128x128: return launch_x<X128x128_1, true, false, true>(a, s);
-      case XT_64x128: return launch_x<X64x128_1, true, false, true>(a, s);
-      case XT_64x64: return launch_x<X64x64_1, true, false, true>(a, s);
-      case XT_256x64: return launch_x<X256x64_1, true, false, true>(a, s);
+      case XT_256x128: return launch_x<X256x128_1, true, false, true, false, NP>(a, s);
+      case XT_128x128: return launch_x<X128x128_1, true, false, true, false, NP>(a, s);
+      case XT_64x128: return launch_x<X64x128_1, true, false, true, false, NP>(a, s);
+      case XT_64x64: return launch_x<X64x64_1, true, false, true, false, NP>(a, s);
+      case XT_256x64: return launch_x<X256x64_1, true, false, true, false, NP>(a, s);
     }
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
+  // a.np: matrix products per term -- 3 (two-term split, fp32-equivalent; 0 means 3) or 1 (single f16 product, conv_math "f16")
+  if (a.np == 1) return launch_gemm_f16x3_np<1>(a, s);
+  if (a.np != 0 && a.np != 3) return hipErrorInvalidValue;
+  return launch_gemm_f16x3_np<3>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -46,7 +46,8 @@ __device__ __forceinline__ void co_split8(const float (&v)[8], h8& hi, h8& lo) {
 
 // TN = N tiles of 32 columns (9*Cout <= 32*TN).  Weight image = launch_pack_f16x3 of the equivalent 1x1 conv
 // w1[n = tap*Cout + co][ci]: [chunk][unit 4][cout_pad][8 halfs].
-template <int TN>
+// NP = matrix products per term: 3 (two-term split) or 1 (conv_math "f16": x_hi * w_hi only).
+template <int TN, int NP = 3>
 __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   constexpr int NT = 256, NW = 4, BN = 32 * TN;
   constexpr int A_BYTES = CO_NPIX * 64;                 // [4 units][NPIX][16 B]
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
       const int pix = (tid + i * NT) >> 1;
       char* dst = As + buf * A_BYTES + (hf * CO_NPIX + pix) * 16;
       *reinterpret_cast<h8*>(dst) = hi;
-      *reinterpret_cast<h8*>(dst + 2 * CO_NPIX * 16) = lo;
+      if (NP == 3) *reinterpret_cast<h8*>(dst + 2 * CO_NPIX * 16) = lo;
     }
   };
 
@@ -155,14 +156,18 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
     for (int t = 0; t < TMW; ++t) {
       if (wave + NW * t >= CO_MT) continue;             // wave-uniform
       const h8 ah = *reinterpret_cast<const h8*>(A + arow[t] * 16);
-      const h8 al = *reinterpret_cast<const h8*>(A + arow[t] * 16 + 2 * CO_NPIX * 16);
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         const h8 bh = *reinterpret_cast<const h8*>(B + n * 32 * 16);
-        const h8 bl = *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][n], 0, 0, 0);
+        if (NP == 3) {
+          const h8 al = *reinterpret_cast<const h8*>(A + arow[t] * 16 + 2 * CO_NPIX * 16);
+          const h8 bl = *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][n], 0, 0, 0);
+        } else {
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
+        }
       }
     }
     if (more) stage(chunk + 1, (chunk + 1) & 1);
@@ -210,17 +215,22 @@ bool conv_out_supported(const GemmArgs& a) {
          a.Cout * 9 <= 32 /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile: 581 vs 587 us */ && (a.Cin & 15) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
 }
 
-hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
-  if (!conv_out_supported(a)) return hipErrorInvalidValue;
+template <int NP>
+static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
   const size_t smem = conv_out_smem(a.Cin, 1);
   dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<1, NP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(conv_out_kernel<1>, grid, block, smem, s, a);
+  hipLaunchKernelGGL((conv_out_kernel<1, NP>), grid, block, smem, s, a);
   return hipGetLastError();
+}
+
+hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
+  if (!conv_out_supported(a)) return hipErrorInvalidValue;
+  return a.np == 1 ? launch_conv_out_np<1>(a, s) : launch_conv_out_np<3>(a, s);
 }
 
 }  // namespace asyrp

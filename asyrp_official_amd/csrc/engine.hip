@@ -167,7 +167,8 @@ struct asyrp_engine {
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
   struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; };
   std::unordered_map<std::string, XW> xw;        // conv weight name -> f16x3 image (conv_f16x3.hip)
-  int math = MATH_F16X3;                         // cfg.conv_math
+  int math = MATH_F16X3;                         // cfg.conv_math (kernel family)
+  int np = 3;                                    // f16 family: matrix products per term; 1 for conv_math = ASYRP_MATH_F16
   size_t param_bytes = 0;
   std::unordered_map<std::string, int> tproj_off;   // ResnetBlock / DeltaBlock prefix -> column in tproj
   int tproj_total = 0;
@@ -610,6 +611,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     auto it = c.e->xw.find(wname);
     if (it == c.e->xw.end()) return fail(ASYRP_EKEY, "missing f16x3 weight image " + wname);
     g.math = MATH_F16X3;
+    g.np = c.e->np;
     g.wpk = it->second.p;
     g.cout_pad = it->second.cout_pad;
     g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());   // both powers of two: exact
@@ -776,7 +778,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   b.Hin = H; b.Win = W; b.Hout = H; b.Wout = W; b.Cout = Cout;
   b.ks = 3; b.stride = 1; b.pad = 1; b.silu = 1; b.ld_ps = Cin;
   b.w = P(c, wname); b.ldb = Cout;
-  b.math = MATH_F16X3; b.cout_pad = it->second.cout_pad;
+  b.math = MATH_F16X3; b.np = e->np; b.cout_pad = it->second.cout_pad;
   b.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
   b.ldo = Cout; b.o_zo = (long long)H * W * Cout; b.ZI = 1; b.Z = c.B;
   // this pass: (h | straddling skip channels), + bias + timestep projection + the shared partial
@@ -884,6 +886,7 @@ int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scal
     a.q_off = 0; a.k_off = (heads == 1) ? C : Dh; a.v_off = (heads == 1) ? 2 * C : 2 * Dh;
     a.B = c.B; a.heads = heads; a.T = T; a.Dh = Dh; a.scale = scale;
     a.out = out; a.ldo = C; a.o_img_stride = (long long)T * C; a.o_head_stride = Dh;
+    a.np = c.e->np;
     const double fl = 4.0 * T * (double)T * C * c.B, by = 4.0 * 4.0 * T * (double)C * c.B;
     return run_timed(c, 200000 + T, fl, by, [&]() { return launch_attention_fused(a, c.s); });
   }
@@ -1663,7 +1666,12 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
   asyrp_engine* e = new asyrp_engine();
   e->cfg = *cfg;
+  if (cfg->conv_math != ASYRP_MATH_F16X3 && cfg->conv_math != ASYRP_MATH_F32 && cfg->conv_math != ASYRP_MATH_F16) {
+    delete e;
+    return fail(ASYRP_EINVAL, "unknown conv_math");
+  }
   e->math = (cfg->conv_math == ASYRP_MATH_F32) ? MATH_F32 : MATH_F16X3;
+  e->np = (cfg->conv_math == ASYRP_MATH_F16) ? 1 : 3;   // the single-product mode runs the f16x3 family's kernels with NP = 1
   e->max_batch = max_batch;
   e->device = device;
   if (cfg->family == ASYRP_FAMILY_IDDPM) build_specs_iddpm(e);
@@ -2039,6 +2047,7 @@ int asyrp_train_forward(asyrp_engine* e, const float* xt, int t, int t_next, int
   const asyrp_config& cf = e->cfg;
   if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
     return fail(ASYRP_EINVAL, "training step expects 3 image channels");
+  if (e->np != 3) return fail(ASYRP_EINVAL, "the training step needs conv_math f16x3 or f32 (the single-product f16 mode is inference only)");
   HIPCHK(hipSetDevice(e->device));
   TRY(ensure_bwd_weights(e));
   Ctx c{e, (hipStream_t)stream, B};
@@ -2461,7 +2470,8 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
   g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
   g.math = MATH_F32;
   g.tile = tile;
-  if (conv_math == ASYRP_MATH_F16X3) {
+  if (conv_math == ASYRP_MATH_F16X3 || conv_math == ASYRP_MATH_F16) {
+    g.np = (conv_math == ASYRP_MATH_F16) ? 1 : 3;
     std::vector<float> hw((size_t)Cout * Cin * ksize * ksize);
     HIPCHK(hipMemcpy(hw.data(), weight, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
     float mx = 0.f;
@@ -2685,7 +2695,8 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
   g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
   g.math = MATH_F32; g.tile = tile; g.abl = abl;
-  if (conv_math == ASYRP_MATH_F16X3) {
+  if (conv_math == ASYRP_MATH_F16X3 || conv_math == ASYRP_MATH_F16) {
+    g.np = (conv_math == ASYRP_MATH_F16) ? 1 : 3;
     float* xp;
     TRY(dalloc((f16x3_packed_halfs(Cout, Cin, ksize) + 1) / 2, &xp, 0.f, 10));
     const float wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(wb)));
@@ -2732,6 +2743,7 @@ int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int he
   hipStream_t s = (hipStream_t)stream;
   asyrp_engine tmp_e;   // only the pool (and the math switch) is used
   tmp_e.math = fused ? MATH_F16X3 : MATH_F32;
+  tmp_e.np = (fused == 2) ? 1 : 3;
   Ctx c{&tmp_e, s, B};
   float *q2 = nullptr, *o2 = nullptr;
   int rc = tmp_e.pool.get((size_t)B * T * 3 * C, &q2);

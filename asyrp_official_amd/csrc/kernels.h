@@ -48,6 +48,7 @@ struct GemmArgs {
                                   //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
   int xmap;                       // set by the f16x3 launcher: XCD-aware block -> tile map (see igemm_f16x3_kernel)
   int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
+  int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
 };
 
 enum { MATH_F16X3 = 0, MATH_F32 = 1 };
@@ -127,6 +128,7 @@ struct AttnArgs {
   int B, heads, T, Dh;
   float scale;
   float* out; int ldo; long long o_img_stride, o_head_stride;
+  int np;                         // matrix products per term: 0 / 3 = two-term split, 1 = single f16 product
 };
 bool attn_fused_supported(int T, int Dh, int ld, int ldo);
 hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s);

@@ -183,8 +183,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--no-parity-check", action="store_true")
-    ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
-                    help="f16x3: 3 x f16 MFMA per product, fp32-equivalent (default); f32: fp32-input MFMA")
+    ap.add_argument("--conv-math", choices=["f16x3", "f32", "f16"], default="f16x3",
+                    help="f16x3: 3 x f16 MFMA per product, fp32-equivalent (default, the line of record); f32: fp32-input MFMA; "
+                         "f16: the FAST mode - one f16 MFMA per product, not fp32-equivalent, reported as a separate line whose "
+                         "dtype says so and whose parity_check carries the measured error instead of gating on the parity tolerance")
     a = ap.parse_args()
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -305,14 +307,17 @@ def main():
                      "inversion": pick(eng.ddim_step(x0, CHECK_INV[0], CHECK_INV[1], learn_sigma=learn_sigma))}
 
     rc = 0
+    NPROD = 1.0 if a.conv_math == "f16" else 3.0       # f16 matrix products issued per algorithmic product
+    fast = a.conv_math == "f16"
     if rank == 0:
         images = B * world * a.steps
         res = {
             "metric": "edited images/sec, CelebA-HQ 256^2 40-step Asyrp, 1/2/4/8 GPU",
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (conv products on f16 MFMA as exact two-term splits, fp32 accumulate)" if a.conv_math == "f16x3"
-            else "f32", "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
+            "dtype": {"f16x3": "f32 (conv products on f16 MFMA as exact two-term splits, fp32 accumulate)", "f32": "f32",
+                      "f16": "f16 (FAST MODE: one f16 MFMA product per term, fp32 accumulate, fp32 activations in HBM; not "
+                             "fp32-equivalent - see parity_check for its measured error)"}[a.conv_math], "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
             "config": {"workload": {"celeba": "CelebA-HQ DDPM", "church": "LSUN-Church DDPM", "afhq": "AFHQ-Dog iDDPM",
                                     "imagenet": "ImageNet ADM (improved_ddpm UNet, 256 base ch)"}[a.config] +
                                    f" 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
@@ -337,11 +342,11 @@ def main():
         if prof and prof["launches"]:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
             if prof["family"] in ("f16x3", "attention"):
-                # the kernel issues 3 f16 matrix products per algorithmic (fp32-equivalent) product: its ceiling for
-                # ALGORITHMIC flops is the dense f16 MFMA peak / 3
-                peak = F16_MFMA_PEAK_TFLOPS / 3.0
+                # the kernel issues NPROD f16 matrix products per algorithmic product (3 in the fp32-equivalent two-term split,
+                # 1 in the fast mode): its ceiling for ALGORITHMIC flops is the dense f16 MFMA peak / NPROD
+                peak = F16_MFMA_PEAK_TFLOPS / NPROD
                 basis = ("dense f16 MFMA 2500 TFLOP/s / 3 matrix instructions per fp32-equivalent product "
-                         "(two-term f16 operand split)")
+                         "(two-term f16 operand split)" if NPROD == 3 else "dense f16 MFMA 2500 TFLOP/s (one product per term)")
             else:
                 peak, basis = F32_MFMA_PEAK_TFLOPS, "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -351,7 +356,7 @@ def main():
                                "flops_per_launch": prof["flops"] / prof["launches"],
                                "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
                                "frac_of_measured_mfma_ceiling": (
-                                   ach / (F16_MFMA_MEASURED_RANDOM_TFLOPS["16x16x32" if "k32" in prof["kernel"] else "32x32x16"] / 3.0)
+                                   ach / (F16_MFMA_MEASURED_RANDOM_TFLOPS["16x16x32" if "k32" in prof["kernel"] else "32x32x16"] / NPROD)
                                    if prof["family"] == "f16x3" else None),
                                "all_gemm_tflops": prof["all_flops"] / (prof["all_ms"] * 1e-3) / 1e12,
                                "gemm_time_share_of_step": prof["all_ms"] * 1e-3 / dt}
@@ -360,7 +365,7 @@ def main():
         for r in sorted(table, key=lambda r: -r["ms"]):
             if not r["launches"] or r["ms"] <= 0:
                 continue
-            mf_peak = F32_MFMA_PEAK_TFLOPS if r["family"] == "f32" else F16_MFMA_PEAK_TFLOPS / 3.0
+            mf_peak = F32_MFMA_PEAK_TFLOPS if r["family"] == "f32" else F16_MFMA_PEAK_TFLOPS / NPROD
             t_mfma = r["flops"] / (mf_peak * 1e12)
             t_hbm = r["bytes"] / (HBM_PEAK_TBS * 1e12)
             sec = r["ms"] * 1e-3
@@ -373,9 +378,9 @@ def main():
             if att:
                 ms_, fl_ = sum(r["ms"] for r in att), sum(r["flops"] for r in att)
                 res["roofline_attention"] = {"bound": "mfma", "achieved": fl_ / (ms_ * 1e-3) / 1e12,
-                                             "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
-                                             "frac": fl_ / (ms_ * 1e-3) / 1e12 / (F16_MFMA_PEAK_TFLOPS / 3.0),
-                                             "f16_mfma_issue_tflops": 3.0 * fl_ / (ms_ * 1e-3) / 1e12,
+                                             "peak": F16_MFMA_PEAK_TFLOPS / NPROD, "unit": "TFLOP/s",
+                                             "frac": fl_ / (ms_ * 1e-3) / 1e12 / (F16_MFMA_PEAK_TFLOPS / NPROD),
+                                             "f16_mfma_issue_tflops": NPROD * fl_ / (ms_ * 1e-3) / 1e12,
                                              "launches_per_step": sum(r["launches"] for r in att) / a.steps,
                                              "share_of_step": ms_ * 1e-3 / dt,
                                              "kernels": sorted({r["kernel"] for r in att})}
@@ -412,7 +417,9 @@ def main():
                                                   "ref_abs_max": float(cv.abs().max()), "atol": atol, "within_tolerance": ok}
                     entry["within_tolerance"] = ok_all
                     parity[f"{which}_step_vs_cpu_{kind}"] = entry
-                    if not ok_all:
+                    if fast:
+                        entry["note"] = "fast mode: the parity tolerance is reported, not required (this line is not the line of record)"
+                    elif not ok_all:
                         rc = 1
         if parity is not None:
             res["parity_check"] = parity

@@ -47,11 +47,17 @@ enum asyrp_family {
                             ImageNet, MetFaces, CelebA-HQ-P2; resblock_updown + scale-shift norm as in every arch dict */
 };
 
-/* Arithmetic of the implicit-GEMM convolutions.  Both are fp32-equivalent (same error class vs the reference's
- * fp32 CPU path, ~1e-6 per UNet forward); they differ in which matrix-core instruction carries the products:
- *   F16X3: operands split into two f16 terms, three v_mfma_f32_32x32x16_f16 per K-slice, fp32 accumulate (default)
- *   F32:   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (1/16 the f16 MFMA rate) */
-enum asyrp_conv_math { ASYRP_MATH_F16X3 = 0, ASYRP_MATH_F32 = 1 };
+/* Arithmetic of the implicit-GEMM convolutions (and of the fused attention kernel).
+ * Parity modes - fp32-equivalent (same error class vs the reference's fp32 CPU path, ~1e-6 per UNet forward); they differ in
+ * which matrix-core instruction carries the products:
+ *   F16X3: operands split into two f16 terms, three f16 MFMAs per K-slice, fp32 accumulate (default)
+ *   F32:   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (1/16 the f16 MFMA rate)
+ * Fast mode - NOT fp32-equivalent, reported separately with its own measured error (bench.py --conv-math f16):
+ *   F16:   ONE f16 MFMA per K-slice: activations and weights rounded to f16 (weights with the same power-of-two pre-scale),
+ *          fp32 accumulate; GroupNorm statistics, softmax, timestep embedding and the DDIM update stay fp32/double as in the
+ *          parity modes.  The reference's own reduced-precision hook is models/improved_ddpm/unet.py:660-674 (convert_to_fp16,
+ *          unused by its scripts).  Inference only (the training step refuses it). */
+enum asyrp_conv_math { ASYRP_MATH_F16X3 = 0, ASYRP_MATH_F32 = 1, ASYRP_MATH_F16 = 2 };
 
 /* Hyper-parameters.  DDPM reads them from configs/<dataset>.yml `model:` (models/ddpm/diffusion.py:331-337);
  * iDDPM/ADM from the arch dicts (models/improved_ddpm/script_util.py:5-42). */
@@ -263,7 +269,7 @@ int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, 
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
  * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T].
  * fused != 0: the one-launch f16x3 kernel (csrc/attention.hip; T <= 1024, head width <= 512, multiple of 16), the engine's
- * default; fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
+ * default (fused == 2: its single-product form, conv_math f16); fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream);
 
 #ifdef ASYRP_BENCH_HOOKS
