@@ -787,11 +787,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   <8, 8, 8>: 64 x 128 for the 8 x 8-pixel layers (8 x 8 patch = one image, a 16-row fragment = two patch rows, wave = 64
 //              pixels x 16 channels; 46 KB: three workgroups per CU)
 //   <8, 8, 16, 2>: 64 x 128 at stride 2 (4 x 16 output patch, 9 x 33 halo, wave = 64 pixels x 16 channels; DDPM Downsample)
-template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1>
+//   <8, 2, 16, 1, 2>: the POLYPHASE form of the main tile for "nearest x2, then 3x3" (Upsample.conv, models/ddpm/diffusion.py:84-87;
+//              ResBlock(up=True).in_layers.2, improved_ddpm/unet.py:281-284).  Output pixel (2i+py, 2j+px) of that convolution
+//              sees only the 2 x 2 source pixels (i+py-1 .. i+py, j+px-1 .. j+px): the nine taps collapse, per output phase
+//              (py, px), into four taps whose weights are sums of the original ones (built on the host at parameter upload).
+//              One workgroup computes a 16 x 16 patch of SOURCE positions for one phase (17 x 17 halo, 4 taps per chunk) and
+//              scatters to the stride-2 output grid: 4/9 of the matrix work of the 3x3 form, no duplicated halo staging.
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
+  static constexpr int KS = KS_, NTAPS = KS * KS;              // 3 x 3 taps, or the 2 x 2 taps of one output phase
   static constexpr int PW = PW_, FR = 16 / PW;                 // FR patch rows per 16-row fragment
-  static constexpr int BM = WM * 64, BN = 128, PH = BM / PW, TW = (PW - 1) * STRIDE + 3, TH = (PH - 1) * STRIDE + 3;
+  static constexpr int BM = WM * 64, BN = 128, PH = BM / PW, TW = (PW - 1) * STRIDE + KS, TH = (PH - 1) * STRIDE + KS;
   static constexpr int NPIX = TH * TW;                         // halo pixels (324 for the main tile)
   static constexpr int PLANE = (NPIX + 15) / 16 * 16;          // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
   static constexpr int A_BYTES = 4 * PLANE * 16;               // [4 units][PLANE][16 B]
@@ -805,6 +812,7 @@ struct K32Cfg {
   static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
   static_assert(NA <= 2 && NSC <= 2 && NSC <= NA, "staging registers");
   static_assert(PW == 16 || PW == 8, "a fragment is one or two patch rows");
+  static_assert(KS == 3 || (KS == 2 && STRIDE == 1), "polyphase form: 2 x 2 taps at stride 1");
 };
 
 // SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
@@ -832,7 +840,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
-  const int zo = blockIdx.z;
+  // polyphase form: blockIdx.z = image * 4 + output phase (py, px); Hout x Wout are the SOURCE dimensions (the M space)
+  constexpr bool POLY = (T::KS == 2);
+  constexpr int NTAPS = T::NTAPS, KW = T::KS;
+  static_assert(!(POLY && SC), "the polyphase form has no fused shortcut");
+  const int zo = POLY ? (int)blockIdx.z >> 2 : (int)blockIdx.z;
+  const int phy = POLY ? ((int)blockIdx.z >> 1) & 1 : 0, phx = POLY ? (int)blockIdx.z & 1 : 0;
   const int n0 = blockIdx.y * BN;
   int bx = blockIdx.x;
   if (p.xmap) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);   // XCD-aware block -> tile map (see igemm_f16x3_kernel)
@@ -844,7 +857,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const int ldps = p.ld_ps ? p.ld_ps : p.Cin;
   const float* __restrict__ ps = p.pscale ? p.pscale + (long long)zo * ldps : nullptr;
   const float* __restrict__ psh = p.pshift ? p.pshift + (long long)zo * ldps : nullptr;
-  const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk);
+  const char* __restrict__ wpk = reinterpret_cast<const char*>(p.wpk) + (POLY ? (long long)(phy * 2 + phx) * p.w_phase : 0);
   const int Cout = p.Cout, c0s = p.c0;
   const int nch = p.Cin / XKC;               // even (launcher: Cin % 32 == 0)
 
@@ -858,7 +871,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     int off = -2;
     if (u < NU) {
       const int iy = pix / TW, ix = pix - iy * TW;
-      const int gy = oy0 * STRIDE - p.pad + iy, gx = ox0 * STRIDE - p.pad + ix;
+      // polyphase: phase 0 reads source rows (i-1, i), phase 1 rows (i, i+1): the halo origin moves with the phase
+      const int gy = oy0 * STRIDE - (POLY ? 1 - phy : p.pad) + iy, gx = ox0 * STRIDE - (POLY ? 1 - phx : p.pad) + ix;
       const int Hu = p.Hin << p.ups, Wu = p.Win << p.ups;
       off = (gy >= 0 && gy < Hu && gx >= 0 && gx < Wu) ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : -1;
     }
@@ -1047,26 +1061,26 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
-  const int nsteps3 = nch * 9 / 2;
+  const int nsteps3 = nch * NTAPS / 2;
   const int nsc = SC ? p.Cin2 / (2 * XKC) : 0;
   const int nsteps = nsteps3 + nsc;
   int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
   for (int s = 0; s < nsteps3; ++s) {
     if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
-    if (t1 == 9) { t1 = 0; ++c1; }
-    const int ky0 = (t0 * 11) >> 5, ky1 = (t1 * 11) >> 5;     // t / 3 for t in 0..8
-    const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - 3 * ky0)) * 16;
-    const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - 3 * ky1)) * 16;
+    if (t1 == NTAPS) { t1 = 0; ++c1; }
+    const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;   // t / KW
+    const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - KW * ky0)) * 16;
+    const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - KW * ky1)) * 16;
     const char* A = As + a_lane + (tp ? offA1 : offA0);
     const char* B = Bs + (s & 1) * SLOT_BYTES + b_lane;
     mma_step(A + 0, A_TM, 2 * PLANE * 16, B);
     // two slices on
     t0 += 2;
-    if (t0 >= 9) { t0 -= 9; ++c0; }
+    if (t0 >= NTAPS) { t0 -= NTAPS; ++c0; }
     // the halo tile of the chunk the NEXT step's second slice belongs to must be in LDS before the barrier below; its
     // buffer held chunk need-2, last read at least one barrier ago
-    const int need = (t0 == 8) ? c0 + 1 : c0;
+    const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
     if (need > staged && need < nch && !(abl & 8)) {
       gload_A(need);
       write_A(need, need & 1);
@@ -1123,7 +1137,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
         const int m = 4 * g + r;                                   // row of the 16 x 16 block
         const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
         ok[r] = nok && (full || (oy < p.Hout && ox < p.Wout));
-        pixel[r] = oy * p.Wout + ox;
+        pixel[r] = POLY ? (2 * oy + phy) * (2 * p.Wout) + 2 * ox + phx : oy * p.Wout + ox;
         rv[r] = 0.f;
         if (rz && ok[r]) rv[r] = p.rups ? rz[((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) * p.ldr + n] : rz[pixel[r] * p.ldr + n];
       }
@@ -1156,7 +1170,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
           s1 += red[((size_t)w * BN + c) * 2];
           s2 += red[((size_t)w * BN + c) * 2 + 1];
         }
-        double* dst = p.stats + (((size_t)zo * gridDim.x + bx) * Cout + n0 + c) * 2;
+        // (polyphase: blockIdx.z = image * 4 + phase, i.e. 4 * gridDim.x statistics rows per image)
+        double* dst = p.stats + (((size_t)blockIdx.z * gridDim.x + bx) * Cout + n0 + c) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -1213,11 +1228,12 @@ using K32Main = K32Cfg<8, 2>;
 using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
+using K32Up = K32Cfg<8, 2, 16, 1, 2>;
 template <class T, bool SC, bool ABL = false, int NP = 3>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
   const int gy = (a.Cout + T::BN - 1) / T::BN;
-  dim3 grid(gx, gy, a.Z), block(T::NT);
+  dim3 grid(gx, gy, a.Z * (T::KS == 2 ? 4 : 1)), block(T::NT);   // polyphase form: one z-slice per (image, output phase)
   GemmArgs ax = a;
   ax.xmap = (xcd_map_enabled() && gx >= 16 && (gx & 7) == 0 && (gy * (long long)gx) % 8 == 0) ? 1 : 0;
   static bool attr_set[16] = {};
@@ -1299,7 +1315,13 @@ static int requested_tile_x(const GemmArgs& a) {
 }
 
 // the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
+// polyphase launch (GemmArgs.poly): nearest x2 + 3x3 as four 2x2-tap convolutions on the source grid (K32Cfg<8, 2, 16, 1, 2>)
+static bool k32up_ok(const GemmArgs& a) {
+  return a.poly && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && !a.resid && (a.Cin & 31) == 0 && a.Cin >= 32 &&
+         a.Hin == a.Hout && a.Win == a.Wout && a.w_phase > 0 && is_vec(a);
+}
 static int eff_tile_x(const GemmArgs& a) {
+  if (a.poly) return XT_256x128K32UP;
   if (a.stride == 2) return (k32s2_ok(a) && k32_preferred() && a.tile != XT_64x128) ? XT_64x128K32S2 : XT_64x128;
   int t = requested_tile_x(a);
   if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
@@ -1315,7 +1337,7 @@ static int eff_tile_x(const GemmArgs& a) {
 int gemm_resolve_tile_x(const GemmArgs& a) { return eff_tile_x(a); }
 
 bool gemm_can_fuse_shortcut(const GemmArgs& a) {
-  if (a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
+  if (a.poly || a.ks != 3 || a.stride != 1 || a.ups || a.abl || !a.s0 || a.Cin2 <= 0) return false;
   if (((a.sc0 | a.sc1 | a.lds0 | a.lds1 | a.Cin2) & 15) || ((((uintptr_t)a.s0) | ((uintptr_t)a.s1)) & 15)) return false;
   const int t = eff_tile_x(a);
   return is_vec(a) && (t == XT_256x128 || t == XT_256x128W8 || t == XT_256x128K32 || t == XT_128x128K32 || t == XT_64x128K32);
@@ -1323,6 +1345,7 @@ bool gemm_can_fuse_shortcut(const GemmArgs& a) {
 
 int gemm_mblocks(const GemmArgs& a) {
   int bm;
+  if (a.poly) return 4 * ((a.Hout + K32Up::PH - 1) / K32Up::PH) * ((a.Wout + K32Up::PW - 1) / K32Up::PW);   // 4 phases per image
   if (eff_tile_x(a) == XT_64x128K32S2) return ((a.Hout + K32S2::PH - 1) / K32S2::PH) * ((a.Wout + K32S2::PW - 1) / K32S2::PW);
   switch (eff_tile_x(a)) {
     case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32:
@@ -1369,6 +1392,7 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
     if (a.ks == 3) return big ? launch_x<X256x128_3plain, false, false, false, false, NP>(a, s) : launch_x<X64x128_3plain, false, false, false, false, NP>(a, s);
     return big ? launch_x<X256x128_1plain, false, false, false, false, NP>(a, s) : launch_x<X64x128_1plain, false, false, false, false, NP>(a, s);
   }
+  if (a.poly) return k32up_ok(a) ? launch_k32<K32Up, false, false, NP>(a, s) : hipErrorInvalidValue;
   if (a.abl && NP != 3) return hipErrorInvalidValue;
   if (a.abl) {   // timing ablations of the main tile: instantiated in the profiling library only (libasyrp_hip_bench.so)
 #ifdef ASYRP_BENCH_HOOKS

@@ -165,7 +165,7 @@ struct asyrp_engine {
   bool bwd_weights = false;             // transposed decoder weight images built (first training call)
 
   std::unordered_map<std::string, float*> dev;   // packed parameter -> device pointer
-  struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; };
+  struct XW { void* p = nullptr; float wscale = 1.f; int cout_pad = 0; size_t halfs = 0; size_t phase_halfs = 0; /* polyphase images */ };
   std::unordered_map<std::string, XW> xw;        // conv weight name -> f16x3 image (conv_f16x3.hip)
   int math = MATH_F16X3;                         // cfg.conv_math (kernel family)
   int np = 3;                                    // f16 family: matrix products per term; 1 for conv_math = ASYRP_MATH_F16
@@ -490,6 +490,61 @@ int pack_x3_fused(asyrp_engine* e, const std::string& name, const std::vector<fl
   return 0;
 }
 
+// "nearest x2, then 3x3" collapses, per output phase (py, px), into a 2x2 convolution on the source grid (conv_f16x3.hip,
+// K32Cfg<8, 2, 16, 1, 2>): output row 2i+py reads source rows (2i+py+ky-1)>>1 for ky = 0..2, i.e. rows {i-1: ky=0 | i: ky=1,2} for
+// py = 0 and {i: ky=0,1 | i+1: ky=2} for py = 1 (same along x).  -> [4 phases][Cout][Cin][2][2], the sums of the taps that meet
+// on one source pixel (added in fp32: the rounding of the sum is the one difference from evaluating the nine taps apart).
+std::vector<float> polyphase_weights(const float* w, int cout, int cin) {
+  std::vector<float> o((size_t)4 * cout * cin * 4, 0.f);
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px)
+      for (size_t oc = 0; oc < (size_t)cout * cin; ++oc) {
+        const float* k = w + oc * 9;
+        float* d = o.data() + (((size_t)(py * 2 + px) * cout * cin) + oc) * 4;
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int a = ((py + ky - 1 + 2) >> 1) - 1 + (1 - py), b = ((px + kx - 1 + 2) >> 1) - 1 + (1 - px);   // tap slot 0/1
+            d[a * 2 + b] += k[ky * 3 + kx];
+          }
+      }
+  return o;
+}
+
+// the four phase images of one up-sampled 3x3 conv under `name` + "#up": one allocation, phases phase_halfs apart, one scale
+int pack_x3_up(asyrp_engine* e, const std::string& name, const std::vector<float>& w, int cout, int cin) {
+  const std::vector<float> wp = polyphase_weights(w.data(), cout, cin);
+  float mx = 0.f;
+  for (float v : wp) mx = std::max(mx, std::fabs(v));
+  float wscale = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx)));
+  const size_t ph = f16x3_packed_halfs(cout, cin, 2);
+  const std::string key = name + "#up";
+  asyrp_engine::XW x;
+  auto it = e->xw.find(key);
+  if (it != e->xw.end() && it->second.halfs == 4 * ph) {
+    x = it->second;
+  } else {
+    if (it != e->xw.end()) { (void)hipFree(it->second.p); e->param_bytes -= it->second.halfs * 2; }
+    HIPCHK(hipMalloc(&x.p, 4 * ph * 2));
+    x.halfs = 4 * ph;
+    e->param_bytes += 4 * ph * 2;
+  }
+  x.phase_halfs = ph;
+  x.wscale = wscale;
+  x.cout_pad = ((cout + 127) / 128) * 128;
+  float* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, wp.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(tmp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t le = hipSuccess;
+  for (int q = 0; q < 4 && le == hipSuccess; ++q)
+    le = launch_pack_f16x3(tmp + (size_t)q * cout * cin * 4, reinterpret_cast<char*>(x.p) + (size_t)q * ph * 2, cout, cin, 2, wscale, nullptr);
+  hipError_t se = hipDeviceSynchronize();
+  (void)hipFree(tmp);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "polyphase weight packing failed for " + name);
+  e->xw[key] = x;
+  return 0;
+}
+
 // conv weight [Cout][Cin][k][k] -> GEMM B operand [k*k][Cin][Cout]
 std::vector<float> pack_conv(const std::vector<float>& w, int cout, int cin, int k) {
   std::vector<float> o((size_t)k * k * cin * cout);
@@ -651,6 +706,20 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
           if (c.e->prof_on) gemm_work(g, &fl, &by);
           return run_timed(c, 300000 + Cout, fl, by, [&]() { return launch_conv_out(t, c.s); });
         }
+      }
+    }
+    // nearest x2 + 3x3: the polyphase form (four 2x2-tap phases on the source grid, 4/9 of the products) when the layer has its
+    // phase images and runs on the main tile; the training forward keeps the 3x3 form its backward pass is written against
+    if (ups && ks == 3 && stride == 1 && !c.tape && !resid && !sc0) {
+      auto uit = c.e->xw.find(wname + "#up");
+      if (uit != c.e->xw.end() && (g.Cin & 31) == 0 && (long long)Hin * Win >= 1024) {
+        g.poly = 1;
+        g.ups = 0;
+        g.Hout = Hin; g.Wout = Win;                       // the M space is the source grid; `out` stays 2H x 2W
+        g.wpk = uit->second.p;
+        g.w_phase = (long long)uit->second.phase_halfs * 2;
+        g.cout_pad = uit->second.cout_pad;
+        g.alpha = 1.0f / (uit->second.wscale * f16x3_act_scale());
       }
     }
     // 8x8 layers: M x N has fewer tiles than the chip has CUs and K is thousands deep -> split K over 8 workgroups per
@@ -1645,6 +1714,18 @@ int weight_grad(Ctx& c, const float* dY, int Cout, const float* X, int Cin, long
 
 }  // namespace
 
+namespace {
+// weights of the 3x3 convolutions that read a nearest-x2 up-sampled tensor: DDPM `up.<i>.upsample.conv` (models/ddpm/diffusion.py:
+// 84-87), iDDPM / ADM `in_layers.2` of a ResBlock(up=True) (models/improved_ddpm/unet.py:232-234, 281-284)
+bool is_upsampled_conv(const asyrp_engine* e, const std::string& key) {
+  if (e->cfg.family != ASYRP_FAMILY_IDDPM) return key.find(".upsample.conv.weight") != std::string::npos;
+  for (const auto& blk : e->out_blocks)
+    for (const auto& L : blk)
+      if (L.type == 1 && L.mode == 2 && key == L.p + ".in_layers.2.weight") return true;
+  return false;
+}
+}  // namespace
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -1821,6 +1902,8 @@ int asyrp_finalize_params(asyrp_engine* e) {
         if (isd(s.key)) {
           TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
           if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+          // convolutions applied to a nearest-x2 up-sampled tensor: the four phase-collapsed 2x2 images (polyphase form)
+          if (e->math == MATH_F16X3 && k == 3 && cin % 32 == 0 && is_upsampled_conv(e, s.key)) TRY(pack_x3_up(e, s.key, v, cout, cin));
           // the UNet's last conv (conv_out / out.2): a second image with the 9 taps folded into N for conv_out.hip
           if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= 32 &&
               cin % 16 == 0 && cin <= 256) {
@@ -2484,6 +2567,26 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
     g.wpk = xp;
     g.cout_pad = ((Cout + 127) / 128) * 128;
     g.alpha = 1.0f / (wscale * f16x3_act_scale());
+    if (tile == XT_256x128K32UP) {   // polyphase form of "nearest x2 then 3x3": the four phase-collapsed 2x2 images
+      if (ksize != 3 || stride != 1 || !upsample || (Cin & 31) || rs) {
+        for (void* p : tmp) (void)hipFree(p);
+        return fail(ASYRP_EINVAL, "shape not covered by the polyphase tile (3x3, stride 1, upsample, Cin % 32 == 0, no residual)");
+      }
+      const std::vector<float> wp = polyphase_weights(hw.data(), Cout, Cin);
+      float mp = 0.f;
+      for (float v : wp) mp = std::max(mp, std::fabs(v));
+      const float ps = (mp > 0.f && std::isfinite(mp)) ? std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mp))) : 1.f;
+      const size_t ph = f16x3_packed_halfs(Cout, Cin, 2);
+      float *wpd, *xpu;
+      TRY(dalloc(wp.size(), &wpd));
+      HIPCHK(hipMemcpy(wpd, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+      TRY(dalloc((4 * ph + 1) / 2, &xpu));
+      for (int q = 0; q < 4; ++q)
+        HIPCHK(launch_pack_f16x3(wpd + (size_t)q * Cout * Cin * 4, reinterpret_cast<char*>(xpu) + (size_t)q * ph * 2, Cout, Cin, 2, ps, s));
+      g.poly = 1; g.ups = 0; g.Hout = H; g.Wout = W; g.tile = 0;
+      g.wpk = xpu; g.w_phase = (long long)ph * 2;
+      g.alpha = 1.0f / (ps * f16x3_act_scale());
+    }
     if (tile == 13) {   // the taps-in-N kernel of the UNet's last conv (conv_out.hip): its own weight image
       std::vector<float> w1((size_t)9 * Cout * Cin);
       for (int co = 0; co < Cout; ++co)
@@ -2703,6 +2806,15 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
     HIPCHK(launch_pack_f16x3(w, xp, Cout, Cin, ksize, wscale, s));
     g.math = MATH_F16X3; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
     g.alpha = 1.0f / (wscale * f16x3_act_scale());
+    if (tile == XT_256x128K32UP) {   // polyphase form (timing only: four 2x2 images packed from the same synthetic weights)
+      if (!upsample || ksize != 3 || stride != 1 || residual || (Cin & 31)) return fail(ASYRP_EINVAL, "polyphase tile: upsample 3x3 only");
+      const size_t ph = f16x3_packed_halfs(Cout, Cin, 2);
+      float* xpu;
+      TRY(dalloc((4 * ph + 1) / 2, &xpu, 0.f, 12));
+      for (int q = 0; q < 4; ++q)
+        HIPCHK(launch_pack_f16x3(w + (size_t)q * Cout * Cin, reinterpret_cast<char*>(xpu) + (size_t)q * ph * 2, Cout, Cin, 2, wscale, s));
+      g.poly = 1; g.ups = 0; g.Hout = H; g.Wout = W; g.tile = 0; g.wpk = xpu; g.w_phase = (long long)ph * 2;
+    }
   }
   const int sk = (tile == 0) ? splitk_factor(g) : 1;   // as the engine does when it picks the tile itself
   if (sk > 1) {

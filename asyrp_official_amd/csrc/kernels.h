@@ -48,6 +48,10 @@ struct GemmArgs {
                                   //   [Z][gemm_mblocks()][Cout][2]; consumed by launch_gn_finalize2
   int xmap;                       // set by the f16x3 launcher: XCD-aware block -> tile map (see igemm_f16x3_kernel)
   int abl;                        // ablation mask of the profiling build of the main tile (scripts/conv_bench.py); 0 in the product
+  // polyphase launch of "nearest x2 then 3x3" (f16x3 family, K32Cfg<8, 2, 16, 1, 2>): Hin = Hout, Win = Wout are the SOURCE dimensions,
+  // ups = 0, the output tensor is (2 Hout) x (2 Wout); wpk holds four images [phase py*2+px][chunk][4 taps][4 units][cout_pad][8]
+  // of the phase-collapsed 2x2 weights, w_phase bytes apart; statistics rows: 4 * tiles per image (gemm_mblocks)
+  int poly; long long w_phase;
   int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
 };
 
@@ -62,6 +66,7 @@ enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4,
        XT_128x128K32 = 8 /* its 128-pixel form (8 x 16 patch, 8 waves of 64 pixels x 32 channels) */,
        XT_64x128K32 = 9 /* 8 x 8 patch (one 8 x 8 image), 8 waves of 64 pixels x 16 channels */,
        XT_64x128K32S2 = 10 /* stride 2 (DDPM Downsample): 4 x 16 output patch, 8 waves of 64 pixels x 16 channels */,
+       XT_256x128K32UP = 11 /* polyphase form of the main tile: nearest x2 + 3x3 as four 2x2-tap phases on the source grid */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math

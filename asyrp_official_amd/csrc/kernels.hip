@@ -418,8 +418,9 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
 }
 
 void gemm_work(const GemmArgs& a, double* flops, double* bytes) {
-  const double M = (double)a.Hout * a.Wout * a.Z;
-  const double K = (double)a.ks * a.ks * a.Cin + (a.s0 ? (double)a.Cin2 : 0.0);   // + fused 1x1 shortcut
+  // polyphase launch: 4 output phases per source position, 4 collapsed taps each (the products actually issued)
+  const double M = (double)a.Hout * a.Wout * a.Z * (a.poly ? 4.0 : 1.0);
+  const double K = (a.poly ? 4.0 : (double)a.ks * a.ks) * a.Cin + (a.s0 ? (double)a.Cin2 : 0.0);   // + fused 1x1 shortcut
   *flops = 2.0 * M * a.Cout * K;
   double in_elems = (double)a.Hin * a.Win * a.Cin * a.Z;
   if (a.s0) in_elems += M * a.Cin2;

@@ -229,7 +229,9 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  *                             6=256x128 8-wave on v_mfma_f32_32x32x16_f16, 7=the same tile on v_mfma_f32_16x16x32_f16
  *                             (igemm_f16x3_k32_kernel: the default for 3x3 stride-1 layers of 32x32 pixels and more whose
  *                             channel counts are multiples of 32), 8=its 128-pixel form (16x16-pixel layers), 9=its 8x8-patch form, 10=its stride-2 form,
- *                             12=256x32),
+ *                             11=the polyphase form of tile 7 for "nearest x2 then 3x3" (Upsample.conv / ResBlock(up=True)): four
+ *                             phase-collapsed 2x2-tap convolutions on the source grid, 4/9 of the products; its FLOPs are
+ *                             counted as issued (4 taps), 12=256x32),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */
@@ -249,6 +251,7 @@ int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms
  *   gn_weight/gn_bias non-null: act = swish(GroupNorm32(x, eps)) (silu=1) or GroupNorm32 only (silu=0).
  *   conv_math: enum asyrp_conv_math; tile: 0 = the launcher's own choice, else force one tile shape of that
  *   kernel family so every compiled variant can be parity-tested (tile 7 falls back to tile 6 when Cin % 32 != 0);
+ *   tile 11 = the polyphase form for upsample != 0 (3x3, Cin % 32 == 0, no residual);
  *   tile 13 = the taps-in-N kernel of the UNet's last
  *   convolution (csrc/conv_out.hip: 3x3, stride 1, Cout*9 <= 32, GroupNorm + SiLU prologue required). */
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,

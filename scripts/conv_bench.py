@@ -82,6 +82,19 @@ if __name__ == "__main__":
             med = {t: sorted(r[t])[2] for t in tiles}
             print(f"  {Ch}->{Ch} @{H}->{H // 2}: " + "  ".join(f"t{t} {med[t]:5.1f}" for t in tiles), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "poly":      # nearest x2 + 3x3: the 3x3 form over the virtual up-sampling (0) vs polyphase (11)
+        print(f"-- A/B interleaved, B={B}: up-sampled 3x3 conv, launcher's 3x3 form (tile 0) vs the polyphase form (tile 11); us per launch")
+        for math in ("f16x3", "f16"):
+            for (H, Ch, pro) in ((128, 128, 0), (64, 256, 0), (32, 256, 0), (128, 128, 1), (64, 256, 1)):
+                tiles = (0, 11)
+                r = {t: [] for t in tiles}
+                for rnd in range(5):
+                    for t in tiles:
+                        r[t].append(run(H, Ch, 0, Ch, 3, ups=1, pro=pro, tile=t, math=math, iters=6)[0] * 1e3)
+                med = {t: sorted(r[t])[2] for t in tiles}
+                print(f"  {math:5s} {Ch}->{Ch} @{H}->{2 * H} prologue={pro}: " + "  ".join(f"t{t} {med[t]:7.1f} us" for t in tiles) +
+                      f"   ratio {med[11] / med[0]:.3f}", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")

@@ -381,3 +381,26 @@ def test_attention(B, C, T, heads, fused):
         w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
         ref = torch.einsum("bts,bcs->bct", F.softmax(w.float(), dim=-1), v).reshape(B, -1, T)
     assert_close(out.cpu(), ref, what="attention", **TIGHT)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pro", [(2, 64, 160, 40, 24, True), (1, 128, 128, 32, 32, False), (2, 256, 256, 16, 48, True),
+                                                 (1, 32, 96, 17, 33, False)])
+def test_polyphase_upsample_conv(B, Cin, Cout, H, W, pro, math):
+    """Tile 11: nearest x2 + 3x3 (Upsample.conv, models/ddpm/diffusion.py:84-87; ResBlock(up=True).in_layers.2) as four phase-
+    collapsed 2x2-tap convolutions on the source grid; partial tiles on both axes, partial N tile, with and without the
+    GroupNorm + SiLU prologue, odd source sizes.  f16x3: the parity tolerance; f16: the fast mode's."""
+    x = hash_normal(f"pp.x.{Cin}.{H}.{W}", (B, Cin, H, W))
+    w = hash_uniform(f"pp.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"pp.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform("pp.g", (Cin,)), 0.1 * hash_uniform("pp.be", (Cin,))) if pro else None
+    got = hip_conv(x, w, b, upsample=True, gn=gn, silu=pro, math=math, tile=11)
+    want = ref_conv(x, w, b, upsample=True, gn=gn, silu=pro)
+    assert got.shape == (B, Cout, 2 * H, 2 * W)
+    if math == "f16x3":
+        assert_close(got, want, what="polyphase x2 conv", **TIGHT)
+        # and against the 3x3 form over the virtually up-sampled input (the launcher's default for this op hook)
+        assert_close(got, hip_conv(x, w, b, upsample=True, gn=gn, silu=pro, math=math), what="polyphase vs 3x3 form", **TIGHT)
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
