@@ -288,4 +288,324 @@ hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s) {
   return wide ? launch_attn<8, 4>(a, s) : launch_attn<8, 2>(a, s);
 }
 
+// =====================================================================================================================
+// attn_planes_kernel -- the fused attention of the f16 engine since round 3 (the kernel above ran at
+// 0.08 of its MFMA bound because every K row and every V column was fetched with exposed latency and split into f16 hi/lo in
+// registers by each of the 8 workgroups that needed it).
+//   * the q|k|v projection's epilogue already wrote q, k as f16 hi/lo PLANES and v TRANSPOSED ([channel][token]) hi/lo
+//     (GemmArgs::o16h ...), so every matrix operand here is a plain 16-byte load: no conversion work, no gathers;
+//   * v_mfma_f32_16x16x32_f16 (the instruction the convolutions moved to in round 2), three products per term (one when NP = 1);
+//   * one workgroup = 32 queries of one (image, head), 8 waves (2 per SIMD).
+//       phase 1  S^T = K Q^T: the waves split the KEYS (16-key tiles, wave w takes tiles w, w+8, ...); A = K rows straight from
+//                global memory into registers (one 16-B load per plane, prefetched one 32-channel step ahead), B = Q staged once
+//                into LDS; the transposed product leaves each lane holding ITS query against 4 keys per tile;
+//       softmax  over the whole score row (T <= 1024 lives in the 8 waves' registers): max / sum through lane shuffles and a small
+//                LDS exchange, p = exp(s - max) / sum in the reference's order; p * 2^10 is split hi/lo and written to LDS in
+//                the B-operand layout of phase 2;
+//       phase 2  O^T = V^T P^T: the waves split the OUTPUT CHANNELS (16-channel tile x 16-query tile items), each over ALL keys,
+//                so there is no cross-wave reduction of partial outputs; A = V^T rows (16 B of consecutive keys per plane),
+//                B = P from LDS; each lane ends with 4 consecutive channels of one query: a float4 store.
+// Every K / V element is loaded once per workgroup.  T % 32 == 0, Dh % 32 == 0 (every reference configuration: T = 64 / 256 /
+// 1024, Dh = 64 / 512); other shapes stay on attn_f16x3_kernel.
+// =====================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int NKTW /* 16-key tiles per wave */, int NP>
+__global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T, Dh = p.Dh, ld = p.ld16;
+  const int nks = Dh >> 5, nsteps = T >> 5;       // 32-channel steps of Q K^T, 32-key steps of P V
+  const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
+  const long long qk_base = (long long)b * T * ld + (long long)head * p.head_stride;
+  const _Float16* __restrict__ QH = p.qkh + qk_base + p.q_off;
+  const _Float16* __restrict__ QL = p.qkl + qk_base + p.q_off;
+  const _Float16* __restrict__ KH = p.qkh + qk_base + p.k_off;
+  const _Float16* __restrict__ KL = p.qkl + qk_base + p.k_off;
+  const long long vt_base = ((long long)b * p.heads + head) * Dh * T;
+  const _Float16* __restrict__ VH = p.vth + vt_base;
+  const _Float16* __restrict__ VL = p.vtl + vt_base;
+
+  // LDS: Qs [plane][ks][kq][32 q][8 halfs] | Ps [plane][qt][step][kq][16 q][8 halfs] | red [2][8 waves][32]
+  char* const Qs = smem;
+  char* const Ps = smem + (size_t)2 * nks * 4 * 32 * 16;
+  float* const red = reinterpret_cast<float*>(Ps + (size_t)2 * 2 * nsteps * 4 * 16 * 16);
+
+  // ---- stage Q: one 16-B copy per (plane, ks, kq, q) ----
+  for (int i = tid; i < (NP == 1 ? 1 : 2) * nks * 4 * 32; i += 512) {
+    const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
+    const int row = min(q0 + q, T - 1);
+    const _Float16* src = (pl ? QL : QH) + (long long)row * ld + ks * 32 + kq * 8;
+    *reinterpret_cast<h8*>(Qs + ((size_t)((pl * nks + ks) * 4 + kq) * 32 + q) * 16) = *reinterpret_cast<const h8*>(src);
+  }
+  __syncthreads();
+
+  // ---- phase 1: S^T = K Q^T, this wave's key tiles ----
+  f32x4 s[NKTW][2];
+#pragma unroll
+  for (int i = 0; i < NKTW; ++i)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[i][qt][r] = 0.f;
+  int koff[NKTW];
+  bool kval[NKTW];
+#pragma unroll
+  for (int i = 0; i < NKTW; ++i) {
+    const int kt = wave + 8 * i;
+    kval[i] = (kt * 16 < T);                          // wave-uniform (T % 16 == 0)
+    koff[i] = min(kt * 16 + r16, T - 1) * ld + g * 8;
+  }
+  if (kval[0]) {
+    h8 kh[2][NKTW], kl[2][NKTW];
+    auto loadK = [&](int ks, int buf) {
+#pragma unroll
+      for (int i = 0; i < NKTW; ++i) {
+        kh[buf][i] = *reinterpret_cast<const h8*>(KH + koff[i] + ks * 32);
+        if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(KL + koff[i] + ks * 32);
+      }
+    };
+    loadK(0, 0);
+    for (int ks = 0; ks < nks; ks += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k1 = ks + u;
+        if (k1 < nks) {
+          if (k1 + 1 < nks) loadK(k1 + 1, u ^ 1);
+          h8 qh[2], ql[2];
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            qh[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)(k1 * 4 + g) * 32 + qt * 16 + r16) * 16);
+            if (NP == 3) ql[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)((nks + k1) * 4 + g) * 32 + qt * 16 + r16) * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < NKTW; ++i) {
+            if (!kval[i]) continue;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[u][i], qh[qt], s[i][qt], 0, 0, 0);
+              s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], qh[qt], s[i][qt], 0, 0, 0);
+              if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], ql[qt], s[i][qt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- softmax over the keys of query (q0 + qt*16 + r16): accumulator element r of tile i is key (wave + 8i)*16 + 4g + r ----
+  float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int i = 0; i < NKTW; ++i)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = kval[i] ? s[i][qt][r] * p.scale : -INFINITY;
+        s[i][qt][r] = v;
+        mx[qt] = fmaxf(mx[qt], v);
+      }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16));
+    mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32));
+    if (g == 0) red[wave * 32 + qt * 16 + r16] = mx[qt];
+  }
+  __syncthreads();
+  float sum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float m = red[qt * 16 + r16];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w * 32 + qt * 16 + r16]);
+    mx[qt] = m;
+#pragma unroll
+    for (int i = 0; i < NKTW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[i][qt][r] - m);     // exp(-inf) = 0 for the tiles this wave does not own
+        s[i][qt][r] = e;
+        sum[qt] += e;
+      }
+    sum[qt] += __shfl_xor(sum[qt], 16);
+    sum[qt] += __shfl_xor(sum[qt], 32);
+    if (g == 0) red[256 + wave * 32 + qt * 16 + r16] = sum[qt];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[256 + w * 32 + qt * 16 + r16];   // fixed order: deterministic
+    sum[qt] = t;
+  }
+  // p * 2^10 as hi/lo -> LDS in the B-operand layout of phase 2: k group kq of a 32-key step = keys 8kq .. 8kq+7
+#pragma unroll
+  for (int i = 0; i < NKTW; ++i) {
+    if (!kval[i]) continue;
+    const int kt = wave + 8 * i;
+    const int step = kt >> 1, kk = (kt & 1) * 16 + 4 * g;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      h4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __fdiv_rn(s[i][qt][r], sum[qt]) * P_SCALE;
+        const _Float16 hh = (_Float16)v;
+        hi[r] = hh;
+        lo[r] = (_Float16)(v - (float)hh);
+      }
+      char* dst = Ps + ((size_t)((qt * nsteps + step) * 4 + (kk >> 3)) * 16 + r16) * 16 + (kk & 7) * 2;
+      *reinterpret_cast<h4*>(dst) = hi;
+      if (NP == 3) *reinterpret_cast<h4*>(dst + (size_t)2 * nsteps * 4 * 16 * 16) = lo;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: O^T = V^T P^T; items (16-channel tile dt, query tile qt), wave w takes items w, w+8, ... two at a time ----
+  const int nitems = (Dh >> 4) * 2;
+  float* __restrict__ outz = p.out + (long long)b * p.o_img_stride + (long long)head * p.o_head_stride;
+  for (int it0 = wave; it0 < nitems; it0 += 16) {
+    const int it1 = it0 + 8;
+    const bool two = it1 < nitems;                    // wave-uniform
+    const int dt0 = it0 >> 1, qt0 = it0 & 1, dt1 = two ? it1 >> 1 : dt0, qt1 = it1 & 1;
+    const _Float16* vh0 = VH + (long long)(dt0 * 16 + r16) * T + g * 8;
+    const _Float16* vl0 = VL + (long long)(dt0 * 16 + r16) * T + g * 8;
+    const _Float16* vh1 = VH + (long long)(dt1 * 16 + r16) * T + g * 8;
+    const _Float16* vl1 = VL + (long long)(dt1 * 16 + r16) * T + g * 8;
+    const char* pb0 = Ps + ((size_t)(qt0 * nsteps * 4 + g) * 16 + r16) * 16;
+    const char* pb1 = Ps + ((size_t)(qt1 * nsteps * 4 + g) * 16 + r16) * 16;
+    const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    h8 a0h[2], a0l[2], a1h[2], a1l[2];
+    auto loadV = [&](int st, int buf) {
+      a0h[buf] = *reinterpret_cast<const h8*>(vh0 + st * 32);
+      if (NP == 3) a0l[buf] = *reinterpret_cast<const h8*>(vl0 + st * 32);
+      if (two) {
+        a1h[buf] = *reinterpret_cast<const h8*>(vh1 + st * 32);
+        if (NP == 3) a1l[buf] = *reinterpret_cast<const h8*>(vl1 + st * 32);
+      }
+    };
+    loadV(0, 0);
+    for (int st = 0; st < nsteps; st += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s1 = st + u;
+        if (s1 < nsteps) {
+          if (s1 + 1 < nsteps) loadV(s1 + 1, u ^ 1);
+          const h8 p0h = *reinterpret_cast<const h8*>(pb0 + (size_t)s1 * 4 * 16 * 16);
+          if (NP == 3) {
+            const h8 p0l = *reinterpret_cast<const h8*>(pb0 + (size_t)s1 * 4 * 16 * 16 + plo);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[u], p0h, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0h, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0l, o0, 0, 0, 0);
+          } else {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0h, o0, 0, 0, 0);
+          }
+          if (two) {
+            const h8 p1h = *reinterpret_cast<const h8*>(pb1 + (size_t)s1 * 4 * 16 * 16);
+            if (NP == 3) {
+              const h8 p1l = *reinterpret_cast<const h8*>(pb1 + (size_t)s1 * 4 * 16 * 16 + plo);
+              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[u], p1h, o1, 0, 0, 0);
+              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1h, o1, 0, 0, 0);
+              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1l, o1, 0, 0, 0);
+            } else {
+              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1h, o1, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // accumulator: column = query r16 of the tile, rows = channels 4g .. 4g+3 of the tile: 16 contiguous bytes of out[q][.]
+    {
+      const int q = q0 + qt0 * 16 + r16;
+      if (q < T) {
+        float4 v = make_float4(o0[0] * P_UNSCALE, o0[1] * P_UNSCALE, o0[2] * P_UNSCALE, o0[3] * P_UNSCALE);
+        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt0 * 16 + 4 * g) = v;
+      }
+    }
+    if (two) {
+      const int q = q0 + qt1 * 16 + r16;
+      if (q < T) {
+        float4 v = make_float4(o1[0] * P_UNSCALE, o1[1] * P_UNSCALE, o1[2] * P_UNSCALE, o1[3] * P_UNSCALE);
+        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt1 * 16 + 4 * g) = v;
+      }
+    }
+  }
+}
+
+static size_t attn_planes_smem(int T, int Dh) {
+  return (size_t)2 * (Dh >> 5) * 4 * 32 * 16 + (size_t)2 * 2 * (T >> 5) * 4 * 16 * 16 + 2 * 8 * 32 * sizeof(float);
+}
+
+bool attn_planes_supported(int T, int Dh) {
+  return T >= 32 && T <= 1024 && (T & 31) == 0 && Dh >= 32 && Dh <= 512 && (Dh & 31) == 0 && attn_planes_smem(T, Dh) <= 160 * 1024;
+}
+
+template <int NKTW, int NP>
+static hipError_t launch_attn_planes_t(const AttnArgs& a, hipStream_t s) {
+  const size_t smem = attn_planes_smem(a.T, a.Dh);
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_planes_kernel<NKTW, NP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  dim3 grid(a.T / 32, a.heads, a.B);
+  hipLaunchKernelGGL((attn_planes_kernel<NKTW, NP>), grid, dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention_planes(const AttnArgs& a, hipStream_t s) {
+  if (!attn_planes_supported(a.T, a.Dh) || !a.qkh || !a.vth || (a.np != 1 && (!a.qkl || !a.vtl))) return hipErrorInvalidValue;
+  if ((a.ld16 & 7) || (a.q_off & 7) || (a.k_off & 7) || (a.head_stride & 7) || (a.ldo & 3) || (a.o_head_stride & 3) ||
+      ((uintptr_t)a.qkh & 15) || ((uintptr_t)a.vth & 15) || ((uintptr_t)a.out & 15))
+    return hipErrorInvalidValue;
+  const int nkt = (a.T / 16 + 7) / 8;               // 16-key tiles per wave
+  const bool one = (a.np == 1);
+  if (nkt <= 1) return one ? launch_attn_planes_t<1, 1>(a, s) : launch_attn_planes_t<1, 3>(a, s);
+  if (nkt <= 2) return one ? launch_attn_planes_t<2, 1>(a, s) : launch_attn_planes_t<2, 3>(a, s);
+  if (nkt <= 4) return one ? launch_attn_planes_t<4, 1>(a, s) : launch_attn_planes_t<4, 3>(a, s);
+  return one ? launch_attn_planes_t<8, 1>(a, s) : launch_attn_planes_t<8, 3>(a, s);
+}
+
+// fp32 q|k|v rows -> the split planes (what the projection's epilogue writes in the engine); one thread per element
+__global__ void qkv_to_planes_kernel(const float* __restrict__ qkv, int ld, int T, int C3, int v_mod, int v_off, int v_dh,
+                                     _Float16* o16h, _Float16* o16l, _Float16* vth, _Float16* vtl, long long total) {
+  const int Cv = (C3 / v_mod) * v_dh;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % C3);
+    const long long bt = i / C3;
+    const int t = (int)(bt % T);
+    const long long b = bt / T;
+    const float v = __builtin_amdgcn_fmed3f(qkv[bt * ld + n], -AH_MAX, AH_MAX);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const int nm = n % v_mod;
+    if (nm >= v_off) {
+      const long long o = (b * Cv + (n / v_mod) * v_dh + nm - v_off) * T + t;
+      vth[o] = h;
+      vtl[o] = l;
+    } else {
+      o16h[bt * C3 + n] = h;
+      o16l[bt * C3 + n] = l;
+    }
+  }
+}
+
+hipError_t launch_qkv_to_planes(const float* qkv, int ld, int B, int T, int C3, int v_mod, int v_off, int v_dh, _Float16* o16h,
+                                _Float16* o16l, _Float16* vth, _Float16* vtl, hipStream_t s) {
+  const long long total = (long long)B * T * C3;
+  long long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(qkv_to_planes_kernel, dim3((unsigned)nb), dim3(256), 0, s, qkv, ld, T, C3, v_mod, v_off, v_dh, o16h, o16l, vth,
+                     vtl, total);
+  return hipGetLastError();
+}
+
 }  // namespace asyrp

@@ -632,6 +632,58 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       d[1] = s2;
     }
   };
+  if (KS == 1 && p.o16h) {
+    // split-plane output (the q|k|v projection of an attention block, GemmArgs::o16h): every value leaves as an exact two-term
+    // f16 split; q and k rows into [pixel][ld16] planes, the v channels transposed into [channel][pixel] planes.  Accumulator
+    // elements 4j .. 4j+3 of a lane are 4 consecutive pixels of one channel: one 8-byte store per plane in the transposed part.
+    _Float16* __restrict__ oh = p.o16h + (long long)zo * p.o16_zo;
+    _Float16* __restrict__ ol = p.o16l + (long long)zo * p.o16_zo;
+    _Float16* __restrict__ vh = p.vth + (long long)zo * p.vt_zo;
+    _Float16* __restrict__ vl = p.vtl + (long long)zo * p.vt_zo;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);
+      if (n >= Cout) continue;
+      const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
+      const int nm = n % p.v_mod;
+      const bool isv = nm >= p.v_off;
+      const long long vrow = (long long)((n / p.v_mod) * p.v_dh + nm - p.v_off) * HWo;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pix = m0 + (wm * TM + tm) * 32 + 8 * j + 4 * kh;
+          typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+          h4v hi, lo;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = __builtin_amdgcn_fmed3f(acc[tm][tn][4 * j + q] * p.alpha + add, -H_MAX, H_MAX);
+            const _Float16 hh = (_Float16)v;
+            hi[q] = hh;
+            lo[q] = (_Float16)(v - (float)hh);
+          }
+          if (isv) {
+            if (pix + 3 < HWo) {
+              *reinterpret_cast<h4v*>(vh + vrow + pix) = hi;
+              if (vl) *reinterpret_cast<h4v*>(vl + vrow + pix) = lo;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (pix + q < HWo) { vh[vrow + pix + q] = hi[q]; if (vl) vl[vrow + pix + q] = lo[q]; }
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (pix + q < HWo) {
+                oh[(long long)(pix + q) * p.ld16 + n] = hi[q];
+                if (ol) ol[(long long)(pix + q) * p.ld16 + n] = lo[q];
+              }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (sk > 1) {   // split-K: raw partial sums; bias / residual / statistics belong to launch_splitk_reduce
     float* __restrict__ part = p.part + ((size_t)(ks_id * (int)gridDim.z + zo) * HWo) * Cout;
 #pragma unroll

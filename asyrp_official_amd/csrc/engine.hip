@@ -627,6 +627,12 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
   return run_timed(c, c.e->prof_on ? variant_of(g) : 0, fl, by, [&]() { return launch_gemm(g, c.s); });
 }
 
+// A/B switch of the polyphase form of the up-sampled 3x3 convolutions (ASYRP_POLYPHASE=0 keeps the 3x3 form over the virtual
+// up-sampling); like the other switches its value is recorded in bench.py's line
+static bool polyphase_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_POLYPHASE"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
@@ -710,7 +716,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     }
     // nearest x2 + 3x3: the polyphase form (four 2x2-tap phases on the source grid, 4/9 of the products) when the layer has its
     // phase images and runs on the main tile; the training forward keeps the 3x3 form its backward pass is written against
-    if (ups && ks == 3 && stride == 1 && !c.tape && !resid && !sc0) {
+    if (ups && ks == 3 && stride == 1 && !c.tape && !resid && !sc0 && polyphase_enabled()) {
       auto uit = c.e->xw.find(wname + "#up");
       if (uit != c.e->xw.end() && (g.Cin & 31) == 0 && (long long)Hin * Win >= 1024) {
         g.poly = 1;
@@ -989,10 +995,85 @@ int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scal
   return 0;
 }
 
+// ---- split-plane attention path (attention.hip, attn_planes_kernel): the q|k|v projection writes f16 hi/lo planes (v transposed)
+// from its epilogue and the attention kernel multiplies them without any conversion or gather work.  ASYRP_ATTN=old keeps the
+// round-2 kernel (fp32 q|k|v, operands split in registers) for A/B; recorded in bench.py's line like the other switches.
+struct QkvPlanes { _Float16 *h = nullptr, *l = nullptr, *vth = nullptr, *vtl = nullptr; float* raw[4] = {nullptr, nullptr, nullptr, nullptr}; int ld16 = 0; };
+static bool attn_planes_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_ATTN"); return !(e && e[0] == 'o'); }();
+  return on;
+}
+void drop_planes(Ctx& c, QkvPlanes& pl) {
+  for (float*& r : pl.raw) { if (r) c.e->pool.put(r); r = nullptr; }
+}
+// q|k|v = conv1x1(GN(x)) [B][T][3C] as planes; heads == 1: channel blocks q|k|v (DDPM AttnBlock), else the legacy per-head
+// [q|k|v] order (QKVAttentionLegacy, improved_ddpm/unet.py:389)
+int qkv_planes_conv(Ctx& c, const Act& x, const std::string& wname, const std::string& bname, int heads, const float* sc,
+                    const float* sh, QkvPlanes* pl) {
+  asyrp_engine* e = c.e;
+  const int C = x.C, T = x.H * x.W, Dh = C / heads;
+  auto it = e->xw.find(wname);
+  if (it == e->xw.end()) return fail(ASYRP_EKEY, "missing f16x3 weight image " + wname);
+  const size_t nqk = ((size_t)c.B * T * 3 * C + 1) / 2, nv = ((size_t)c.B * C * T + 1) / 2;     // halfs -> floats
+  const bool lo = (e->np == 3);
+  TRY(e->pool.get(nqk, &pl->raw[0]));
+  TRY(e->pool.get(nv, &pl->raw[2]));
+  if (lo) {
+    TRY(e->pool.get(nqk, &pl->raw[1]));
+    TRY(e->pool.get(nv, &pl->raw[3]));
+  }
+  pl->h = reinterpret_cast<_Float16*>(pl->raw[0]); pl->l = reinterpret_cast<_Float16*>(pl->raw[1]);
+  pl->vth = reinterpret_cast<_Float16*>(pl->raw[2]); pl->vtl = reinterpret_cast<_Float16*>(pl->raw[3]);
+  pl->ld16 = 3 * C;
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = x.p; g.c0 = C; g.lda0 = C; g.a0_zo = x.per_image();
+  g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.Cin = C; g.Cout = 3 * C; g.ks = 1; g.stride = 1;
+  g.pscale = sc; g.pshift = sh; g.silu = 0;
+  g.w = P(c, wname); g.ldb = 3 * C; g.bias = P(c, bname);
+  g.ZI = 1; g.Z = c.B; g.ldo = 3 * C;
+  g.math = MATH_F16X3; g.np = e->np; g.wpk = it->second.p; g.cout_pad = it->second.cout_pad;
+  g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
+  g.o16h = pl->h; g.o16l = pl->l; g.vth = pl->vth; g.vtl = pl->vtl; g.ld16 = 3 * C;
+  g.o16_zo = (long long)T * 3 * C; g.vt_zo = (long long)C * T;
+  if (heads == 1) { g.v_mod = 3 * C; g.v_off = 2 * C; g.v_dh = C; }
+  else { g.v_mod = 3 * Dh; g.v_off = 2 * Dh; g.v_dh = Dh; }
+  if (!g.bias) return fail(ASYRP_EKEY, "missing bias " + bname);
+  return run_gemm(c, g);
+}
+int attention_planes(Ctx& c, const QkvPlanes& pl, int C, int T, int heads, float scale, float* out /*[B][T][C]*/) {
+  const int Dh = C / heads;
+  AttnArgs a;
+  memset(&a, 0, sizeof a);
+  a.qkh = pl.h; a.qkl = pl.l; a.vth = pl.vth; a.vtl = pl.vtl; a.ld16 = pl.ld16;
+  a.head_stride = (heads == 1) ? 0 : 3 * Dh;
+  a.q_off = 0; a.k_off = (heads == 1) ? C : Dh;
+  a.B = c.B; a.heads = heads; a.T = T; a.Dh = Dh; a.scale = scale;
+  a.out = out; a.ldo = C; a.o_img_stride = (long long)T * C; a.o_head_stride = Dh;
+  a.np = c.e->np;
+  const double fl = 4.0 * T * (double)T * C * c.B, by = 4.0 * 4.0 * T * (double)C * c.B;
+  return run_timed(c, 210000 + T, fl, by, [&]() { return launch_attention_planes(a, c.s); });   // 21xxxx: the split-plane kernel
+}
+static bool use_attn_planes(const Ctx& c, int T, int Dh) {
+  return c.e->math == MATH_F16X3 && !c.tape && attn_planes_enabled() && attn_planes_supported(T, Dh);
+}
+
 // AttnBlock (models/ddpm/diffusion.py:200-225): GN -> fused q|k|v 1x1 -> attention -> proj_out -> + x
 int attnblock(Ctx& c, const std::string& p, const Act& x, Act* out) {
   float *sc, *sh, *mr = nullptr, *Pk = nullptr;
   TRY(gn(c, x, nullptr, p + ".norm", 1e-6f, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
+  if (use_attn_planes(c, x.H * x.W, x.C)) {
+    QkvPlanes pl;
+    TRY(qkv_planes_conv(c, x, p + ".qkv.weight", p + ".qkv.bias", 1, sc, sh, &pl));
+    c.e->pool.put(sc); c.e->pool.put(sh);
+    Act o;
+    TRY(new_act(c, x.C, x.H, x.W, &o));
+    TRY(attention_planes(c, pl, x.C, x.H * x.W, 1, 1.0f / std::sqrt((float)x.C), o.p));
+    drop_planes(c, pl);
+    TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr, &x, out, true));
+    drop(c, o);
+    return 0;
+  }
   Act qkv;
   TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
   c.e->pool.put(sc); c.e->pool.put(sh);
@@ -1171,12 +1252,24 @@ int attnblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x, Act* out) {
   const std::string& p = L.p;
   float *sc, *sh, *mr = nullptr, *Pk = nullptr;
   TRY(gn(c, x, nullptr, p + ".norm", EPS_I, &sc, &sh, nullptr, nullptr, 0, c.tape ? &mr : nullptr));
-  Act qkv;
-  TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
-  c.e->pool.put(sc); c.e->pool.put(sh);
   const int nhc = c.e->cfg.num_head_channels;
   if (nhc <= 0 || x.C % nhc) return fail(ASYRP_EINVAL, "num_head_channels must divide the attention width");
   const int heads = x.C / nhc;
+  if (use_attn_planes(c, x.H * x.W, nhc)) {
+    QkvPlanes pl;
+    TRY(qkv_planes_conv(c, x, p + ".qkv.weight", p + ".qkv.bias", heads, sc, sh, &pl));
+    c.e->pool.put(sc); c.e->pool.put(sh);
+    Act o;
+    TRY(new_act(c, x.C, x.H, x.W, &o));
+    TRY(attention_planes(c, pl, x.C, x.H * x.W, heads, 1.0f / std::sqrt((float)nhc), o.p));
+    drop_planes(c, pl);
+    TRY(conv(c, o, nullptr, p + ".proj_out.weight", p + ".proj_out.bias", x.C, 1, 1, 0, nullptr, nullptr, 0, nullptr, &x, out, true));
+    drop(c, o);
+    return 0;
+  }
+  Act qkv;
+  TRY(conv(c, x, nullptr, p + ".qkv.weight", p + ".qkv.bias", 3 * x.C, 1, 1, 0, sc, sh, 0, nullptr, nullptr, &qkv));
+  c.e->pool.put(sc); c.e->pool.put(sh);
   Act o;
   TRY(new_act(c, x.C, x.H, x.W, &o));
   TRY(attention_core(c, qkv.p, x.C, x.H * x.W, heads, 1.0f / std::sqrt((float)nhc), o.p, c.tape ? 1 : 0, c.tape ? &Pk : nullptr));
@@ -2861,7 +2954,25 @@ int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int he
   int rc = tmp_e.pool.get((size_t)B * T * 3 * C, &q2);
   if (!rc) rc = tmp_e.pool.get((size_t)B * T * C, &o2);
   hipError_t le = hipSuccess;
-  if (!rc) {
+  if (!rc && fused >= 3) {   // the split-plane kernel (3: two-term split, 4: single product), planes from the standalone splitter
+    const int Dh = C / heads;
+    if (!attn_planes_supported(T, Dh)) { tmp_e.pool.destroy(); return fail(ASYRP_EINVAL, "shape not covered by attn_planes_kernel"); }
+    tmp_e.np = (fused == 4) ? 1 : 3;
+    QkvPlanes pl;
+    const size_t nqk = ((size_t)B * T * 3 * C + 1) / 2, nv = ((size_t)B * C * T + 1) / 2;
+    for (int i = 0; i < 4 && !rc; ++i) rc = tmp_e.pool.get((i < 2) ? nqk : nv, &pl.raw[i]);
+    if (!rc) {
+      pl.h = reinterpret_cast<_Float16*>(pl.raw[0]); pl.l = reinterpret_cast<_Float16*>(pl.raw[1]);
+      pl.vth = reinterpret_cast<_Float16*>(pl.raw[2]); pl.vtl = reinterpret_cast<_Float16*>(pl.raw[3]);
+      pl.ld16 = 3 * C;
+      le = launch_nchw_to_nhwc(qkv, q2, B, 3 * C, T, s);
+      if (le == hipSuccess)
+        le = launch_qkv_to_planes(q2, 3 * C, B, T, 3 * C, heads == 1 ? 3 * C : 3 * Dh, heads == 1 ? 2 * C : 2 * Dh, heads == 1 ? C : Dh,
+                                  pl.h, pl.l, pl.vth, pl.vtl, s);
+      if (le == hipSuccess) rc = attention_planes(c, pl, C, T, heads, 1.0f / std::sqrt((float)Dh), o2);
+      if (!rc && le == hipSuccess) le = launch_nhwc_to_nchw(o2, C, out, B, C, T, s);
+    }
+  } else if (!rc) {
     le = launch_nchw_to_nhwc(qkv, q2, B, 3 * C, T, s);
     const int Dh = C / heads;
     if (le == hipSuccess) rc = attention_core(c, q2, C, T, heads, 1.0f / std::sqrt((float)Dh), o2);

@@ -52,6 +52,13 @@ struct GemmArgs {
   // ups = 0, the output tensor is (2 Hout) x (2 Wout); wpk holds four images [phase py*2+px][chunk][4 taps][4 units][cout_pad][8]
   // of the phase-collapsed 2x2 weights, w_phase bytes apart; statistics rows: 4 * tiles per image (gemm_mblocks)
   int poly; long long w_phase;
+  // split-plane output (32x32x16 family, 1x1 convolutions; the q|k|v projection of an attention block): instead of fp32 `out`, the
+  // epilogue writes every output value as a two-term f16 split into planes the fused attention kernel (attention.hip,
+  // attn_planes_kernel) consumes without any conversion work: o16h/o16l [zo][pixel][ld16] (same channel indexing as `out` would
+  // have; the v channels are skipped) and the v channels TRANSPOSED, vth/vtl [zo][vc][HW] with vc = (n / v_mod) * v_dh +
+  // (n % v_mod - v_off) for the channels with n % v_mod >= v_off (DDPM q|k|v blocks: v_mod = 3C, v_off = 2C, v_dh = C; the legacy
+  // per-head [q|k|v] order of improved_ddpm/unet.py:389: v_mod = 3 Dh, v_off = 2 Dh, v_dh = Dh)
+  _Float16* o16h; _Float16* o16l; _Float16* vth; _Float16* vtl; int ld16, v_mod, v_off, v_dh; long long o16_zo, vt_zo;
   int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
 };
 
@@ -134,9 +141,17 @@ struct AttnArgs {
   float scale;
   float* out; int ldo; long long o_img_stride, o_head_stride;
   int np;                         // matrix products per term: 0 / 3 = two-term split, 1 = single f16 product
+  // attn_planes_kernel: q|k as f16 hi/lo planes [B][T][ld16] (element (b, t, c) of q at b*T*ld16 + head*head_stride + q_off + t*ld16 + c,
+  // all in halfs) and v transposed, [B][heads*Dh][T]; written by the q|k|v projection's epilogue (GemmArgs::o16h ...)
+  const _Float16* qkh; const _Float16* qkl; const _Float16* vth; const _Float16* vtl; int ld16;
 };
 bool attn_fused_supported(int T, int Dh, int ld, int ldo);
 hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s);
+bool attn_planes_supported(int T, int Dh);
+hipError_t launch_attention_planes(const AttnArgs& a, hipStream_t s);
+// fp32 q|k|v [B][T][ld] -> the split planes above (test hook / standalone use; the engine gets them from the projection's epilogue)
+hipError_t launch_qkv_to_planes(const float* qkv, int ld, int B, int T, int C3, int v_mod, int v_off, int v_dh, _Float16* o16h,
+                                _Float16* o16l, _Float16* vth, _Float16* vtl, hipStream_t s);
 
 // temb = dense1(swish(dense0(sinusoid(t)))) ; sin_first: DDPM [sin|cos] vs iDDPM [cos|sin]
 hipError_t launch_temb_mlp(const float* t, const float* freqs, int half, int sin_first, const float* w0,

@@ -277,6 +277,8 @@ class Engine:
         fam, tid = v // 100000, (v // 1000) % 100
         ks, stride = (v // 100) % 10, (v // 10) % 10
         if fam == 2:
+            if v >= 210000:     # the split-plane kernel (round 3): operands arrive as f16 hi/lo planes from the q|k|v projection
+                return "attention", "asyrp::attn_planes_kernel (T=%d)" % (v - 210000)
             return "attention", "asyrp::attn_f16x3_kernel (T=%d)" % (v - 200000)
         if fam == 3:
             return "f16x3", "asyrp::conv_out_kernel (Cout=%d)" % (v - 300000)

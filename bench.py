@@ -332,7 +332,7 @@ def main():
                                         if world > 1 and backend == "nccl" else None),
                        # A/B switches read by the library from the environment: a non-default kernel choice can never be
                        # benchmarked silently
-                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP")},
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN")},
                        "conv_math": a.conv_math},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
@@ -384,16 +384,34 @@ def main():
                                              "launches_per_step": sum(r["launches"] for r in att) / a.steps,
                                              "share_of_step": ms_ * 1e-3 / dt,
                                              "kernels": sorted({r["kernel"] for r in att})}
-        # HBM traffic of the dominant kernel: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of
-        # this same command (scripts/gpu_traffic.sh -> profiles/traffic_main_tile.json) are reported per launch
-        tpath = os.path.join(ROOT, "profiles", "traffic_main_tile.json")
-        if "roofline" in res and a.config == "celeba" and B == 32 and os.path.exists(tpath):
+        # HBM traffic per kernel family: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of this command
+        # (scripts/gpu_traffic_families.sh -> profiles/traffic_families_<config>_<math>.json) are reported per launch -- but only
+        # when they were taken on THIS library (sha256 stamp): a stale measurement is refused, never pasted
+        tpath = os.path.join(ROOT, "profiles", f"traffic_families_{a.config}_b{B}_{a.conv_math}.json")
+        if "roofline" in res and os.path.exists(tpath):
+            import hashlib
+            from asyrp_official_amd import _lib
             tr = json.load(open(tpath))
-            if tr.get("kernel") == res["roofline"]["kernel"]:
-                res["roofline"]["traffic"] = 1024.0 * (tr.get("fetch_scale", 2.0) * tr["FETCH_SIZE_KB_per_launch"] +
-                                                       tr.get("write_scale", 1.0) * tr["WRITE_SIZE_KB_per_launch"])
-                res["roofline"]["traffic_note"] = tr.get("note", "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) from the "
-                                                         f"committed PMC passes ({tr['round']}); compare with algorithmic_bytes_per_launch")
+            sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+            if tr.get("library_sha256") != sha:
+                res["roofline"]["traffic_note"] = (f"{os.path.basename(tpath)} was measured on another build of the library "
+                                                   f"(sha256 {tr.get('library_sha256', '?')[:12]} != {sha[:12]}): not reported")
+            else:
+                fams_t = tr["families"]
+                hit = fams_t.get(res["roofline"]["kernel"])
+                if hit:
+                    res["roofline"]["traffic"] = hit["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_note"] = (f"HBM bytes per launch = 1024 x (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes "
+                                                       f"over every launch of one edit on this library build ({os.path.basename(tpath)}); "
+                                                       "compare with algorithmic_bytes_per_launch")
+                for fm in res.get("kernel_families", []):
+                    key = fm["kernel"].split(" (")[0]
+                    ht = fams_t.get(key)
+                    if ht and fm["launches_per_step"]:
+                        sec_per_launch = fm["share_of_step"] * dt / a.steps / fm["launches_per_step"]
+                        fm["counter_bytes_per_launch"] = ht["hbm_bytes_per_launch"]
+                        fm["counter_GBps"] = ht["hbm_bytes_per_launch"] / sec_per_launch / 1e9
+                        fm["counter_frac_of_hbm_peak"] = fm["counter_GBps"] / (HBM_PEAK_TBS * 1e3)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], cpu_chk = cpu_baseline(cpu_sd, betas, family, learn_sigma,
                                                          x_check=x0_cpu[chk_rows] if gpu_check is not None else None)

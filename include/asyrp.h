@@ -239,7 +239,7 @@ int asyrp_profile_read(asyrp_engine* e, int* variant, double* ms, int64_t* launc
                        double* all_ms, double* all_flops);
 
 /* Per-kernel-family rows of the same record (variant ids as above; 200000 + T = the fused attention kernel over T tokens
- * with flops = 4*T*T*C per image).  Does not reset the record.  Returns the number of rows written, negative on error. */
+ * with flops = 4*T*T*C per image; 210000 + T = the split-plane attention kernel).  Does not reset the record.  Returns the number of rows written, negative on error. */
 int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms, int64_t* launches, double* flops,
                         double* bytes);
 
@@ -272,7 +272,9 @@ int asyrp_op_resblock_tail(int device, const float* h, int Ch, const float* x0, 
 /* AttnBlock core (models/ddpm/diffusion.py:205-221 / improved_ddpm/unet.py:379-396):
  * qkv [B,3C,T] as q|k|v (heads=1) or the "legacy" per-head [H,(q,k,v),Dh] order, out [B,C,T].
  * fused != 0: the one-launch f16x3 kernel (csrc/attention.hip; T <= 1024, head width <= 512, multiple of 16), the engine's
- * default (fused == 2: its single-product form, conv_math f16); fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
+ * round-2 kernel (fused == 2: its single-product form, conv_math f16); fused == 3 / 4: the split-plane kernel attn_planes_kernel
+ * (the engine's default since round 3 for T % 32 == 0, head width % 32 == 0; 4 = single product), fed here by a standalone
+ * splitter instead of the q|k|v projection's epilogue; fused == 0: fp32-MFMA QK^T -> softmax pass -> fp32-MFMA PV (the conv_math="f32" engine and the fallback). */
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream);
 
 #ifdef ASYRP_BENCH_HOOKS

@@ -404,3 +404,37 @@ def test_polyphase_upsample_conv(B, Cin, Cout, H, W, pro, math):
     else:
         err = float((got - want).abs().max())
         assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+def _attention_ref(qkv, B, C, T, heads):
+    if heads == 1:
+        q, k, v = qkv.double().split(C, dim=1)
+        w = torch.bmm(q.transpose(1, 2), k) * (C ** -0.5)
+        return torch.bmm(v, F.softmax(w, dim=2).transpose(1, 2)).float()
+    ch = C // heads
+    q, k, v = qkv.double().reshape(B * heads, ch * 3, T).split(ch, dim=1)
+    scale = 1 / (ch ** 0.5) ** 0.5
+    w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    return torch.einsum("bts,bcs->bct", F.softmax(w, dim=-1), v).reshape(B, -1, T).float()
+
+
+@pytest.mark.parametrize("B,C,T,heads", [(2, 512, 256, 1), (2, 128, 64, 1), (3, 64, 256, 1), (1, 512, 1024, 8), (2, 256, 256, 4),
+                                         (1, 1024, 64, 16), (2, 512, 512, 8), (1, 96, 32, 3)])
+@pytest.mark.parametrize("fused", [3, 4])
+def test_attention_split_plane_kernel(B, C, T, heads, fused):
+    """attn_planes_kernel (csrc/attention.hip; the engine's attention since round 3): q, k as f16 hi/lo planes, v transposed, both
+    layouts (DDPM q|k|v blocks, legacy per-head [q|k|v]), every key-tile instantiation (T = 32 ... 1024), 1 to 16 heads.
+    fused = 3: the fp32-equivalent three-product form at the parity tolerance; 4: the single-product fast mode at its own."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    qkv = hash_normal(f"att2.{B}.{C}.{T}.{heads}", (B, 3 * C, T))
+    out = torch.empty((B, C, T), device="cuda")
+    qd = qkv.cuda()
+    _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, fused, _p(out), None))
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv, B, C, T, heads)
+    if fused == 3:
+        assert_close(out.cpu(), ref, what="split-plane attention", **TIGHT)
+    else:
+        err, scale = float((out.cpu() - ref).abs().max()), float(ref.abs().max())
+        assert 1e-7 * scale < err <= 4e-3 * scale, (err, scale)
