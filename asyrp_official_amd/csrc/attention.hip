@@ -334,11 +334,26 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   float* const red = reinterpret_cast<float*>(Ps + (size_t)2 * 2 * nsteps * 4 * 16 * 16);
 
   // ---- stage Q: one 16-B copy per (plane, ks, kq, q) ----
-  for (int i = tid; i < (NP == 1 ? 1 : 2) * nks * 4 * 32; i += 512) {
-    const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
-    const int row = min(q0 + q, T - 1);
-    const _Float16* src = (pl ? QL : QH) + (long long)row * ld + ks * 32 + kq * 8;
-    *reinterpret_cast<h8*>(Qs + ((size_t)((pl * nks + ks) * 4 + kq) * 32 + q) * 16) = *reinterpret_cast<const h8*>(src);
+  {
+    const int nq = (NP == 1 ? 1 : 2) * nks * 4 * 32;
+    for (int i0 = tid; i0 < nq; i0 += 4 * 512) {     // four 16-B loads in flight per thread, then the four LDS writes
+      h8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * 512, nq - 1);
+        const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
+        const int row = min(q0 + q, T - 1);
+        v[u] = *reinterpret_cast<const h8*>((pl ? QL : QH) + (long long)row * ld + ks * 32 + kq * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 512;
+        if (i < nq) {
+          const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
+          *reinterpret_cast<h8*>(Qs + ((size_t)((pl * nks + ks) * 4 + kq) * 32 + q) * 16) = v[u];
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -359,7 +374,10 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     koff[i] = min(kt * 16 + r16, T - 1) * ld + g * 8;
   }
   if (kval[0]) {
-    h8 kh[2][NKTW], kl[2][NKTW];
+    // the K rows of the next DK channel steps are in flight while a step feeds the matrix cores: the kernel is bound by the
+    // round trips of these loads (one workgroup per CU, two waves per SIMD), so the ring is as deep as the registers allow
+    constexpr int DK = (NKTW <= 2) ? 4 : 2;
+    h8 kh[DK][NKTW], kl[DK][NKTW];
     auto loadK = [&](int ks, int buf) {
 #pragma unroll
       for (int i = 0; i < NKTW; ++i) {
@@ -367,13 +385,14 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
         if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(KL + koff[i] + ks * 32);
       }
     };
-    loadK(0, 0);
-    for (int ks = 0; ks < nks; ks += 2) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < DK; ++u)
+      if (u < nks) loadK(u, u);
+    for (int ks = 0; ks < nks; ks += DK) {
+#pragma unroll
+      for (int u = 0; u < DK; ++u) {
         const int k1 = ks + u;
         if (k1 < nks) {
-          if (k1 + 1 < nks) loadK(k1 + 1, u ^ 1);
           h8 qh[2], ql[2];
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
@@ -390,6 +409,7 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
               if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], ql[qt], s[i][qt], 0, 0, 0);
             }
           }
+          if (k1 + DK < nks) loadK(k1 + DK, u);
         }
       }
     }
@@ -464,28 +484,34 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   }
   __syncthreads();
 
-  // ---- phase 2: O^T = V^T P^T; items (16-channel tile dt, query tile qt), wave w takes items w, w+8, ... two at a time ----
+  // ---- phase 2: O^T = V^T P^T; items (16-channel tile dt, query tile qt): wave w owns the items w, w+8, ... -- all of query
+  // tile w & 1, channel tiles (w >> 1) + 4j -- and runs up to JC of them side by side: one P fragment per key step feeds JC
+  // accumulators, and the V^T rows of the next step are in flight meanwhile ----
+  constexpr int JC = 8;
   const int nitems = (Dh >> 4) * 2;
+  const int nj = (nitems - wave + 7) >> 3;           // items of this wave (wave-uniform)
+  const int qt = wave & 1, dtb = wave >> 1;
   float* __restrict__ outz = p.out + (long long)b * p.o_img_stride + (long long)head * p.o_head_stride;
-  for (int it0 = wave; it0 < nitems; it0 += 16) {
-    const int it1 = it0 + 8;
-    const bool two = it1 < nitems;                    // wave-uniform
-    const int dt0 = it0 >> 1, qt0 = it0 & 1, dt1 = two ? it1 >> 1 : dt0, qt1 = it1 & 1;
-    const _Float16* vh0 = VH + (long long)(dt0 * 16 + r16) * T + g * 8;
-    const _Float16* vl0 = VL + (long long)(dt0 * 16 + r16) * T + g * 8;
-    const _Float16* vh1 = VH + (long long)(dt1 * 16 + r16) * T + g * 8;
-    const _Float16* vl1 = VL + (long long)(dt1 * 16 + r16) * T + g * 8;
-    const char* pb0 = Ps + ((size_t)(qt0 * nsteps * 4 + g) * 16 + r16) * 16;
-    const char* pb1 = Ps + ((size_t)(qt1 * nsteps * 4 + g) * 16 + r16) * 16;
-    const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-    h8 a0h[2], a0l[2], a1h[2], a1l[2];
+  const char* pb = Ps + ((size_t)(qt * nsteps * 4 + g) * 16 + r16) * 16;
+  const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
+  for (int j0 = 0; j0 < nj; j0 += JC) {
+    f32x4 o[JC];
+    int voff[JC];
+#pragma unroll
+    for (int jj = 0; jj < JC; ++jj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[jj][r] = 0.f;
+      const int dt = dtb + 4 * min(j0 + jj, nj - 1);
+      voff[jj] = (dt * 16 + r16) * T + g * 8;        // (a head's V^T slab is far below 2^31 halfs)
+    }
+    h8 vh[2][JC], vl[2][JC];
     auto loadV = [&](int st, int buf) {
-      a0h[buf] = *reinterpret_cast<const h8*>(vh0 + st * 32);
-      if (NP == 3) a0l[buf] = *reinterpret_cast<const h8*>(vl0 + st * 32);
-      if (two) {
-        a1h[buf] = *reinterpret_cast<const h8*>(vh1 + st * 32);
-        if (NP == 3) a1l[buf] = *reinterpret_cast<const h8*>(vl1 + st * 32);
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        if (j0 + jj < nj) {
+          vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 32);
+          if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 32);
+        }
       }
     };
     loadV(0, 0);
@@ -495,42 +521,28 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
         const int s1 = st + u;
         if (s1 < nsteps) {
           if (s1 + 1 < nsteps) loadV(s1 + 1, u ^ 1);
-          const h8 p0h = *reinterpret_cast<const h8*>(pb0 + (size_t)s1 * 4 * 16 * 16);
-          if (NP == 3) {
-            const h8 p0l = *reinterpret_cast<const h8*>(pb0 + (size_t)s1 * 4 * 16 * 16 + plo);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[u], p0h, o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0h, o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0l, o0, 0, 0, 0);
-          } else {
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[u], p0h, o0, 0, 0, 0);
-          }
-          if (two) {
-            const h8 p1h = *reinterpret_cast<const h8*>(pb1 + (size_t)s1 * 4 * 16 * 16);
-            if (NP == 3) {
-              const h8 p1l = *reinterpret_cast<const h8*>(pb1 + (size_t)s1 * 4 * 16 * 16 + plo);
-              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[u], p1h, o1, 0, 0, 0);
-              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1h, o1, 0, 0, 0);
-              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1l, o1, 0, 0, 0);
-            } else {
-              o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[u], p1h, o1, 0, 0, 0);
+          const h8 ph = *reinterpret_cast<const h8*>(pb + (size_t)s1 * 4 * 16 * 16);
+          h8 pl;
+          if (NP == 3) pl = *reinterpret_cast<const h8*>(pb + (size_t)s1 * 4 * 16 * 16 + plo);
+#pragma unroll
+          for (int jj = 0; jj < JC; ++jj) {
+            if (j0 + jj < nj) {
+              if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[u][jj], ph, o[jj], 0, 0, 0);
+              o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], ph, o[jj], 0, 0, 0);
+              if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], pl, o[jj], 0, 0, 0);
             }
           }
         }
       }
     }
     // accumulator: column = query r16 of the tile, rows = channels 4g .. 4g+3 of the tile: 16 contiguous bytes of out[q][.]
-    {
-      const int q = q0 + qt0 * 16 + r16;
-      if (q < T) {
-        float4 v = make_float4(o0[0] * P_UNSCALE, o0[1] * P_UNSCALE, o0[2] * P_UNSCALE, o0[3] * P_UNSCALE);
-        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt0 * 16 + 4 * g) = v;
-      }
-    }
-    if (two) {
-      const int q = q0 + qt1 * 16 + r16;
-      if (q < T) {
-        float4 v = make_float4(o1[0] * P_UNSCALE, o1[1] * P_UNSCALE, o1[2] * P_UNSCALE, o1[3] * P_UNSCALE);
-        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt1 * 16 + 4 * g) = v;
+    const int q = q0 + qt * 16 + r16;
+#pragma unroll
+    for (int jj = 0; jj < JC; ++jj) {
+      if (j0 + jj < nj && q < T) {
+        const int dt = dtb + 4 * (j0 + jj);
+        float4 v = make_float4(o[jj][0] * P_UNSCALE, o[jj][1] * P_UNSCALE, o[jj][2] * P_UNSCALE, o[jj][3] * P_UNSCALE);
+        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt * 16 + 4 * g) = v;
       }
     }
   }

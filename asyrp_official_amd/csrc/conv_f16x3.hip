@@ -845,7 +845,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //              (py, px), into four taps whose weights are sums of the original ones (built on the host at parameter upload).
 //              One workgroup computes a 16 x 16 patch of SOURCE positions for one phase (17 x 17 halo, 4 taps per chunk) and
 //              scatters to the stride-2 output grid: 4/9 of the matrix work of the 3x3 form, no duplicated halo staging.
-template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3>
+//   RB_ > 2 ("deep ring"): the small forms (8 x 8 patches, stride 2, the 128-pixel form) issue only 12-24 matrix instructions per
+//              wave and K-step, so with the two-slot weight buffer every step ends waiting for a weight slice whose LDS-DMA was
+//              issued one short step earlier: the 8 x 8 layers ran at 1600 cycles per step for 190 cycles of matrix work (0.65 us
+//              = the L2/MALL round trip of a 16 KB slice; profiles/r03c_*: 81 TFLOP/s).  RB slots keep RB-2 slices in flight
+//              behind the one being waited for (LDS-DMA from inline asm with hand-counted s_waitcnt vmcnt, as in the pipelined
+//              32x32x16 loop: hipcc drains vmcnt(0) before any LDS-DMA it can see behind another one); one workgroup per CU.
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3, int RB_ = 2>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
   static constexpr int KS = KS_, NTAPS = KS * KS;              // 3 x 3 taps, or the 2 x 2 taps of one output phase
@@ -859,8 +865,10 @@ struct K32Cfg {
   static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
   static constexpr int NSC = (BM * 4 + NT - 1) / NT;           // shortcut-phase work items per thread
   static constexpr int NPW = 16 / NW;                          // LDS-DMA pieces per wave and step
-  static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
-  static constexpr int MINW = (2 * NW) / 4;                    // two workgroups per CU
+  static constexpr int RB = RB_;                               // weight-slot ring: a slice is in flight for RB-1 K-steps
+  static constexpr size_t SMEM = RB * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
+  static constexpr int MINW = (SMEM <= 76 * 1024 ? 2 : 1) * NW / 4;   // workgroups per CU the LDS admits x waves per SIMD
+  static_assert(RB >= 2 && RB <= 8, "ring depth");
   static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
   static_assert(NA <= 2 && NSC <= 2 && NSC <= NA, "staging registers");
   static_assert(PW == 16 || PW == 8, "a fragment is one or two patch rows");
@@ -886,8 +894,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   constexpr int WCH = BN / WN;                 // output channels per wave
   constexpr int FR = T::FR, STRIDE = T::STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB)
-  char* const As = smem + 2 * SLOT_BYTES;
+  constexpr int RB = T::RB;
+  constexpr bool DEEP = (RB > 2);
+  static_assert(!(DEEP && (SC || ABL)), "the deep-ring loop has no fused-shortcut phase and no ablation switches");
+  char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB for the two-slot forms)
+  char* const As = smem + RB * SLOT_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1002,6 +1013,25 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
+  // deep ring: the same pieces from inline asm (M0 = LDS destination, saved / restored inside the statement), invisible to
+  // hipcc's waitcnt model; the loop below counts them by hand
+  constexpr int NPWE = (NP == 1) ? (8 + T::NW - 1) / T::NW : T::NPW;     // LDS-DMA instructions per wave and K-step
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)Bs);
+  auto issue_slot_asm = [&](int s, int slot) {
+#pragma unroll
+    for (int k = 0; k < NPWE; ++k) {
+      const int pc = wave + k * T::NW;
+      const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
+      const char* src = wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
+      const unsigned dst = lds_base + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64) * 16;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                   : "memory");
+    }
+  };
+
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   // row r16 of row block tm = patch pixel ((wm * 4 + tm) * FR + r16 / PW, r16 % PW)
@@ -1017,7 +1047,14 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
-  issue_slot(0, 0);
+  const int nsteps3 = nch * NTAPS / 2;
+  if (DEEP) {
+#pragma unroll
+    for (int j = 0; j < RB - 1; ++j)
+      if (j < nsteps3) issue_slot_asm(j, j);
+  } else {
+    issue_slot(0, 0);
+  }
   gload_A(0);
   write_A(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1113,11 +1150,50 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
-  const int nsteps3 = nch * NTAPS / 2;
   const int nsc = SC ? p.Cin2 / (2 * XKC) : 0;
   const int nsteps = nsteps3 + nsc;
   int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
-  for (int s = 0; s < nsteps3; ++s) {
+  if (DEEP) {
+    // K loop of the deep-ring forms.  Per step: activation loads of the chunk to stage (if any) -> matrix work on slot s % RB ->
+    // staging pass (the compiler's own vmcnt(0) before it also drains the slices issued in EARLIER steps: they had a whole step
+    // to land) -> LDS-DMA of step s+RB-1 into the slot step s-1 just released -> wait until only the slices YOUNGER than step
+    // s+1's are outstanding -> barrier.
+    int slot = 0;
+    for (int s = 0; s < nsteps3; ++s) {
+      int c1 = c0, t1 = t0 + 1;
+      if (t1 == NTAPS) { t1 = 0; ++c1; }
+      const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;
+      const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - KW * ky0)) * 16;
+      const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - KW * ky1)) * 16;
+      const char* A = As + a_lane + (tp ? offA1 : offA0);
+      const char* B = Bs + slot * SLOT_BYTES + b_lane;
+      t0 += 2;
+      if (t0 >= NTAPS) { t0 -= NTAPS; ++c0; }
+      const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
+      const bool stage = need > staged && need < nch;
+      if (stage) gload_A(need);
+      mma_step(A + 0, A_TM, 2 * PLANE * 16, B);
+      if (stage) {
+        write_A(need, need & 1);
+        staged = need;
+      }
+      if (s + RB - 1 < nsteps3) issue_slot_asm(s + RB - 1, (slot == 0) ? RB - 1 : slot - 1);
+      // slices of steps s+2 .. min(s+RB-1, last) may stay in flight; step s+1's must have landed
+      const int younger = min(RB - 2, nsteps3 - 2 - s);
+      if (younger >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NPWE) : "memory");
+      else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NPWE) : "memory");
+      else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPWE) : "memory");
+      else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPWE) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPWE) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NPWE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes (halo tile) and fragment reads of this slot are complete
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      slot = (slot + 1 == RB) ? 0 : slot + 1;
+    }
+  }
+  for (int s = 0; s < (DEEP ? 0 : nsteps3); ++s) {
     if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
@@ -1281,6 +1357,13 @@ using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
 using K32Up = K32Cfg<8, 2, 16, 1, 2>;
+using K32HalfD = K32Cfg<8, 4, 16, 1, 3, 3>;   // deep-ring forms (no fused shortcut): 3 slots keep two workgroups per CU (72 KB)
+using K32Img8D = K32Cfg<8, 8, 8, 1, 3, 4>;    // 4 slots = 64 KB of LDS-DMA destinations (M0 base below 64 KB), one workgroup per CU
+// A/B switch: ASYRP_DEEP_RING=0 keeps the two-slot forms for the 16x16 / 8x8 layers (recorded in bench.py's line)
+static bool deep_ring_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_DEEP_RING"); return !(e && e[0] == '0'); }();
+  return on;
+}
 template <class T, bool SC, bool ABL = false, int NP = 3>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
@@ -1472,8 +1555,8 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
       case XT_256x32: return launch_x<X256x32_3, true, false, true, false, NP>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true, false, false, false, NP>(a, s);
       case XT_256x128K32: return launch_k32<K32Main, false, false, NP>(a, s);
-      case XT_128x128K32: return launch_k32<K32Half, false, false, NP>(a, s);
-      case XT_64x128K32: return launch_k32<K32Img8, false, false, NP>(a, s);
+      case XT_128x128K32: return deep_ring_enabled() ? launch_k32<K32HalfD, false, false, NP>(a, s) : launch_k32<K32Half, false, false, NP>(a, s);
+      case XT_64x128K32: return deep_ring_enabled() ? launch_k32<K32Img8D, false, false, NP>(a, s) : launch_k32<K32Img8, false, false, NP>(a, s);
     }
   } else {
     switch (tile) {
