@@ -318,7 +318,15 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = p.T, Dh = p.Dh, ld = p.ld16;
   const int nks = Dh >> 5, nsteps = T >> 5;       // 32-channel steps of Q K^T, 32-key steps of P V
-  const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
+  // Workgroups go to the 8 XCDs round-robin by linear id: with the identity map the 8 query blocks of one (image, head) land on 8
+  // different XCDs and each XCD's L2 fetches that image's K and V from HBM on its own (8x the compulsory traffic: the kernel ran
+  // at the HBM rate of those re-reads, profiles/rd3d_*).  XCD k takes a contiguous range of (image, head, query block) instead,
+  // so the query blocks that share K / V meet in one L2.
+  int w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int nblk = gridDim.x * gridDim.y * gridDim.z;
+  if ((nblk & 7) == 0) w = (w & 7) * (nblk >> 3) + (w >> 3);
+  const int qb = w % (int)gridDim.x, hb = w / (int)gridDim.x;
+  const int q0 = qb * 32, head = hb % (int)gridDim.y, b = hb / (int)gridDim.y;
   const long long qk_base = (long long)b * T * ld + (long long)head * p.head_stride;
   const _Float16* __restrict__ QH = p.qkh + qk_base + p.q_off;
   const _Float16* __restrict__ QL = p.qkl + qk_base + p.q_off;

@@ -845,13 +845,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //              (py, px), into four taps whose weights are sums of the original ones (built on the host at parameter upload).
 //              One workgroup computes a 16 x 16 patch of SOURCE positions for one phase (17 x 17 halo, 4 taps per chunk) and
 //              scatters to the stride-2 output grid: 4/9 of the matrix work of the 3x3 form, no duplicated halo staging.
-//   RB_ > 2 ("deep ring"): the small forms (8 x 8 patches, stride 2, the 128-pixel form) issue only 12-24 matrix instructions per
-//              wave and K-step, so with the two-slot weight buffer every step ends waiting for a weight slice whose LDS-DMA was
-//              issued one short step earlier: the 8 x 8 layers ran at 1600 cycles per step for 190 cycles of matrix work (0.65 us
-//              = the L2/MALL round trip of a 16 KB slice; profiles/r03c_*: 81 TFLOP/s).  RB slots keep RB-2 slices in flight
-//              behind the one being waited for (LDS-DMA from inline asm with hand-counted s_waitcnt vmcnt, as in the pipelined
-//              32x32x16 loop: hipcc drains vmcnt(0) before any LDS-DMA it can see behind another one); one workgroup per CU.
-template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3, int RB_ = 2>
+//   BREG_ ("weights through registers"): the small forms (8 x 8 patches, the 128-pixel form, stride 2) issue only 12-24 matrix
+//              instructions per wave and K-step, so their step time is the time the 16 KB weight slice of the NEXT step needs to
+//              arrive -- and LDS-DMA delivers only ~24 GB/s into one CU (MI355X_MICROARCH.md "ldsdma-fill": 0.64 us per 16 KiB;
+//              measured here: 512->512 @8x8 runs at 0.69 us per step for 0.08 us of matrix work, and a deeper LDS-DMA ring made
+//              it 9 % SLOWER, profiles/rd3d_*_NEGATIVE.txt: it is the fill RATE, not its latency).  With BREG the slice travels
+//              global_load_dwordx4 -> registers -> ds_write_b128 (2 x 16 B per thread and step, same LDS image): the ordinary
+//              vector-memory path is not bound by that cadence.  Same products in the same order: bit-identical results.
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3, int BREG_ = 0>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
   static constexpr int KS = KS_, NTAPS = KS * KS;              // 3 x 3 taps, or the 2 x 2 taps of one output phase
@@ -865,10 +866,9 @@ struct K32Cfg {
   static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
   static constexpr int NSC = (BM * 4 + NT - 1) / NT;           // shortcut-phase work items per thread
   static constexpr int NPW = 16 / NW;                          // LDS-DMA pieces per wave and step
-  static constexpr int RB = RB_;                               // weight-slot ring: a slice is in flight for RB-1 K-steps
-  static constexpr size_t SMEM = RB * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
-  static constexpr int MINW = (SMEM <= 76 * 1024 ? 2 : 1) * NW / 4;   // workgroups per CU the LDS admits x waves per SIMD
-  static_assert(RB >= 2 && RB <= 8, "ring depth");
+  static constexpr int BREG = BREG_;     // 0: LDS-DMA; 2: two register sets, two steps ahead; 1: one set, one step ahead (8 VGPRs)
+  static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
+  static constexpr int MINW = (2 * NW) / 4;                    // two workgroups per CU
   static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
   static_assert(NA <= 2 && NSC <= 2 && NSC <= NA, "staging registers");
   static_assert(PW == 16 || PW == 8, "a fragment is one or two patch rows");
@@ -894,11 +894,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   constexpr int WCH = BN / WN;                 // output channels per wave
   constexpr int FR = T::FR, STRIDE = T::STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RB = T::RB;
-  constexpr bool DEEP = (RB > 2);
-  static_assert(!(DEEP && (SC || ABL)), "the deep-ring loop has no fused-shortcut phase and no ablation switches");
-  char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB for the two-slot forms)
-  char* const As = smem + RB * SLOT_BYTES;
+  char* const Bs = smem;                       // LDS-DMA destinations first (M0 base below 64 KB)
+  char* const As = smem + 2 * SLOT_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1013,25 +1010,23 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
-  // deep ring: the same pieces from inline asm (M0 = LDS destination, saved / restored inside the statement), invisible to
-  // hipcc's waitcnt model; the loop below counts them by hand
-  constexpr int NPWE = (NP == 1) ? (8 + T::NW - 1) / T::NW : T::NPW;     // LDS-DMA instructions per wave and K-step
-  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)Bs);
-  auto issue_slot_asm = [&](int s, int slot) {
-#pragma unroll
-    for (int k = 0; k < NPWE; ++k) {
-      const int pc = wave + k * T::NW;
-      const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
-      const char* src = wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16;
-      const unsigned dst = lds_base + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64) * 16;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
-                   : "memory");
-    }
+  // BREG: the same pieces through registers (one 16-B global load per lane and piece, written to the slot before the step's barrier)
+  constexpr int BREG = T::BREG;
+  constexpr int NPWE = (NP == 1) ? (8 + T::NW - 1) / T::NW : T::NPW;
+  // two register sets, plain named values (arrays picked by a run-time index end up in scratch): the slice of step s+2 is in
+  // flight while step s computes
+  static_assert(NPWE <= 2, "weight pieces per wave");
+  float4 b00 = make_float4(0.f, 0.f, 0.f, 0.f), b01 = b00, b10 = b00, b11 = b00;
+  auto b_src = [&](int s, int k) {
+    const int pc = wave + k * T::NW;
+    const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
+    return reinterpret_cast<const float4*>(wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16);
   };
-
+  auto b_dst = [&](int slot, int k) {
+    const int pc = wave + k * T::NW;
+    const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
+    return reinterpret_cast<float4*>(Bs + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64 + lane) * 16);
+  };
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   // row r16 of row block tm = patch pixel ((wm * 4 + tm) * FR + r16 / PW, r16 % PW)
@@ -1047,11 +1042,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
-  const int nsteps3 = nch * NTAPS / 2;
-  if (DEEP) {
-#pragma unroll
-    for (int j = 0; j < RB - 1; ++j)
-      if (j < nsteps3) issue_slot_asm(j, j);
+  static_assert(!(BREG && (SC || ABL)), "the register weight path has no fused-shortcut phase and no ablation switches");
+  if (BREG) {
+    b00 = *b_src(0, 0);
+    if (NPWE > 1) b01 = *b_src(0, 1);
+    *b_dst(0, 0) = b00;
+    if (NPWE > 1) *b_dst(0, 1) = b01;
   } else {
     issue_slot(0, 0);
   }
@@ -1059,6 +1055,10 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   write_A(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (BREG == 2 && p.Cin / XKC * T::NTAPS / 2 > 1) {   // step 1's slice (set 1): written to slot 1 at the end of step 0
+    b10 = *b_src(1, 0);
+    if (NPWE > 1) b11 = *b_src(1, 1);
+  }
 
   // one K = 32 step: 2 * (4 + TN) fragments, 12 * TN matrix instructions (16 and 48 on the main tile); pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
   // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
@@ -1150,51 +1150,20 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
+  const int nsteps3 = nch * NTAPS / 2;
   const int nsc = SC ? p.Cin2 / (2 * XKC) : 0;
   const int nsteps = nsteps3 + nsc;
   int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
-  if (DEEP) {
-    // K loop of the deep-ring forms.  Per step: activation loads of the chunk to stage (if any) -> matrix work on slot s % RB ->
-    // staging pass (the compiler's own vmcnt(0) before it also drains the slices issued in EARLIER steps: they had a whole step
-    // to land) -> LDS-DMA of step s+RB-1 into the slot step s-1 just released -> wait until only the slices YOUNGER than step
-    // s+1's are outstanding -> barrier.
-    int slot = 0;
-    for (int s = 0; s < nsteps3; ++s) {
-      int c1 = c0, t1 = t0 + 1;
-      if (t1 == NTAPS) { t1 = 0; ++c1; }
-      const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;
-      const int offA0 = (c0 & 1) * A_BYTES + (ky0 * TW + (t0 - KW * ky0)) * 16;
-      const int offA1 = (c1 & 1) * A_BYTES + (ky1 * TW + (t1 - KW * ky1)) * 16;
-      const char* A = As + a_lane + (tp ? offA1 : offA0);
-      const char* B = Bs + slot * SLOT_BYTES + b_lane;
-      t0 += 2;
-      if (t0 >= NTAPS) { t0 -= NTAPS; ++c0; }
-      const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
-      const bool stage = need > staged && need < nch;
-      if (stage) gload_A(need);
-      mma_step(A + 0, A_TM, 2 * PLANE * 16, B);
-      if (stage) {
-        write_A(need, need & 1);
-        staged = need;
+  for (int s = 0; s < nsteps3; ++s) {
+    if (BREG == 2) {                                              // set s&1 held step s's slice, stored a step ago
+      if (s + 2 < nsteps) {
+        if (s & 1) { b10 = *b_src(s + 2, 0); if (NPWE > 1) b11 = *b_src(s + 2, 1); }
+        else { b00 = *b_src(s + 2, 0); if (NPWE > 1) b01 = *b_src(s + 2, 1); }
       }
-      if (s + RB - 1 < nsteps3) issue_slot_asm(s + RB - 1, (slot == 0) ? RB - 1 : slot - 1);
-      // slices of steps s+2 .. min(s+RB-1, last) may stay in flight; step s+1's must have landed
-      const int younger = min(RB - 2, nsteps3 - 2 - s);
-      if (younger >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NPWE) : "memory");
-      else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NPWE) : "memory");
-      else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPWE) : "memory");
-      else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPWE) : "memory");
-      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPWE) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NPWE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes (halo tile) and fragment reads of this slot are complete
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      slot = (slot + 1 == RB) ? 0 : slot + 1;
+    } else if (BREG == 1) {                                       // one set: the next step's slice travels under this step's passes
+      if (s + 1 < nsteps) { b00 = *b_src(s + 1, 0); if (NPWE > 1) b01 = *b_src(s + 1, 1); }
     }
-  }
-  for (int s = 0; s < (DEEP ? 0 : nsteps3); ++s) {
-    if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
+    else if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
     const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;   // t / KW
@@ -1214,8 +1183,25 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       write_A(need, need & 1);
       staged = need;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (BREG == 1) {
+      if (s + 1 < nsteps) { *b_dst((s + 1) & 1, 0) = b00; if (NPWE > 1) *b_dst((s + 1) & 1, 1) = b01; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else if (BREG == 2) {
+      // slot (s+1)&1 was last read in step s-1, a barrier ago; its slice was loaded a whole step earlier.  No vmcnt(0) here (the
+      // load of step s+2 stays in flight; hipcc's own counted waits cover the registers it reads) and a raw barrier:
+      // __syncthreads() would drain the vector-memory counter
+      if (s + 1 < nsteps) {
+        if ((s + 1) & 1) { *b_dst(1, 0) = b10; if (NPWE > 1) *b_dst(1, 1) = b11; }
+        else { *b_dst(0, 0) = b00; if (NPWE > 1) *b_dst(0, 1) = b01; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
   if (SC) {
     const char* const Asc = As + (kq * BM + wm * 64 + r16) * 16;
@@ -1357,11 +1343,19 @@ using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
 using K32Up = K32Cfg<8, 2, 16, 1, 2>;
-using K32HalfD = K32Cfg<8, 4, 16, 1, 3, 3>;   // deep-ring forms (no fused shortcut): 3 slots keep two workgroups per CU (72 KB)
-using K32Img8D = K32Cfg<8, 8, 8, 1, 3, 4>;    // 4 slots = 64 KB of LDS-DMA destinations (M0 base below 64 KB), one workgroup per CU
-// A/B switch: ASYRP_DEEP_RING=0 keeps the two-slot forms for the 16x16 / 8x8 layers (recorded in bench.py's line)
-static bool deep_ring_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_DEEP_RING"); return !(e && e[0] == '0'); }();
+using K32HalfR = K32Cfg<8, 4, 16, 1, 3, 2>;     // the register weight path (no fused shortcut)
+using K32Img8R = K32Cfg<8, 8, 8, 1, 3, 2>;
+using K32S2R = K32Cfg<8, 8, 16, 2, 3, 2>;
+using K32MainR = K32Cfg<8, 2, 16, 1, 3, 1>;       // experiment: the main tile with its weights through ONE register set (126 VGPRs)
+// A/B switch: ASYRP_WEIGHT_REGS=0 keeps LDS-DMA for the weights of the 16x16 / 8x8 / stride-2 forms (recorded in bench.py's line)
+// experiment switch (default OFF): ASYRP_MAIN_WEIGHT_REGS=1 runs the plain (no fused shortcut) launches of the main tile with
+// their weights through registers
+static bool main_weight_regs() {
+  static const bool on = [] { const char* e = getenv("ASYRP_MAIN_WEIGHT_REGS"); return e && e[0] == '1'; }();
+  return on;
+}
+static bool weight_regs_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_WEIGHT_REGS"); return !(e && e[0] == '0'); }();
   return on;
 }
 template <class T, bool SC, bool ABL = false, int NP = 3>
@@ -1545,7 +1539,10 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
     return launch_x<X256x128w8_3, true, false, false, true, NP>(a, s);
   }
   if (a.ks == 3) {
-    if (a.stride == 2) return tile == XT_64x128K32S2 ? launch_k32<K32S2, false, false, NP>(a, s) : launch_x<X64x128_3s2, true, false, true, false, NP>(a, s);
+    if (a.stride == 2) {
+      if (tile != XT_64x128K32S2) return launch_x<X64x128_3s2, true, false, true, false, NP>(a, s);
+      return weight_regs_enabled() ? launch_k32<K32S2R, false, false, NP>(a, s) : launch_k32<K32S2, false, false, NP>(a, s);
+    }
     switch (tile) {
       case XT_256x128: return launch_x<X256x128_3, true, false, true, false, NP>(a, s);
       case XT_128x128: return launch_x<X128x128_3, true, false, true, false, NP>(a, s);
@@ -1554,9 +1551,9 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true, false, NP>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true, false, NP>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true, false, false, false, NP>(a, s);
-      case XT_256x128K32: return launch_k32<K32Main, false, false, NP>(a, s);
-      case XT_128x128K32: return deep_ring_enabled() ? launch_k32<K32HalfD, false, false, NP>(a, s) : launch_k32<K32Half, false, false, NP>(a, s);
-      case XT_64x128K32: return deep_ring_enabled() ? launch_k32<K32Img8D, false, false, NP>(a, s) : launch_k32<K32Img8, false, false, NP>(a, s);
+      case XT_256x128K32: return main_weight_regs() ? launch_k32<K32MainR, false, false, NP>(a, s) : launch_k32<K32Main, false, false, NP>(a, s);
+      case XT_128x128K32: return weight_regs_enabled() ? launch_k32<K32HalfR, false, false, NP>(a, s) : launch_k32<K32Half, false, false, NP>(a, s);
+      case XT_64x128K32: return weight_regs_enabled() ? launch_k32<K32Img8R, false, false, NP>(a, s) : launch_k32<K32Img8, false, false, NP>(a, s);
     }
   } else {
     switch (tile) {

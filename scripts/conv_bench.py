@@ -95,13 +95,16 @@ if __name__ == "__main__":
                 print(f"  {math:5s} {Ch}->{Ch} @{H}->{2 * H} prologue={pro}: " + "  ".join(f"t{t} {med[t]:7.1f} us" for t in tiles) +
                       f"   ratio {med[11] / med[0]:.3f}", flush=True)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[2] == "small":     # the 16x16 / 8x8 layers on the launcher's own choice; run once per ASYRP_DEEP_RING value
-        print(f"-- B={B}, ASYRP_DEEP_RING={os.environ.get('ASYRP_DEEP_RING', 'default')}: us per launch, TFLOP/s (median of 5 x 10 launches)")
+    if len(sys.argv) > 2 and sys.argv[2] == "small":     # the 16x16 / 8x8 layers on the launcher's own choice; run once per ASYRP_WEIGHT_REGS value
+        print(f"-- B={B}, ASYRP_WEIGHT_REGS={os.environ.get('ASYRP_WEIGHT_REGS', 'default')}: us per launch, TFLOP/s (median of 5 x 10 launches)")
         for math in ("f16x3", "f16"):
             for (H, Ch, C1, Co, kw) in ((8, 512, 0, 512, {}), (8, 512, 0, 512, dict(res=1)), (16, 512, 0, 512, {}), (16, 512, 512, 512, {}),
                                         (16, 256, 0, 512, {}), (16, 512, 0, 512, dict(res=1))):
                 r = sorted(run(H, Ch, C1, Co, 3, math=math, iters=10, **kw) for _ in range(5))[2]
                 print(f"  {math:5s} {Ch}+{C1}->{Co} @{H} {kw}: {r[0] * 1e3:7.1f} us {r[1]:6.1f} TFLOP/s", flush=True)
+            for (H, Ch) in ((256, 128), (64, 256), (16, 512)):
+                r = sorted(run(H, Ch, 0, Ch, 3, stride=2, pro=0, math=math, iters=8) for _ in range(5))[2]
+                print(f"  {math:5s} stride 2 {Ch}->{Ch} @{H}->{H // 2}: {r[0] * 1e3:7.1f} us {r[1]:6.1f} TFLOP/s", flush=True)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)

@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 (timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -40) > $OUT/pytest.log
 tail -6 $OUT/pytest.log
-(ASYRP_DEEP_RING=0 timeout 200 python scripts/conv_bench.py 32 small 2>&1 | tail -14) > $OUT/ab_small_layers_ring2.txt
-(timeout 200 python scripts/conv_bench.py 32 small 2>&1 | tail -14) > $OUT/ab_small_layers_deep.txt
-cat $OUT/ab_small_layers_ring2.txt $OUT/ab_small_layers_deep.txt
+(ASYRP_WEIGHT_REGS=0 timeout 200 python scripts/conv_bench.py 32 small 2>&1 | tail -20) > $OUT/ab_small_layers_ldsdma.txt
+(timeout 200 python scripts/conv_bench.py 32 small 2>&1 | tail -20) > $OUT/ab_small_layers_regs.txt
+cat $OUT/ab_small_layers_ldsdma.txt $OUT/ab_small_layers_regs.txt
 B="--steps 2 --warmup 1 --no-cpu-baseline --no-parity-check"
 for rnd in 1 2; do
   (timeout 200 python bench.py $B 2>> $OUT/ab.err | tail -1) > $OUT/ab_default_$rnd.json
   (ASYRP_ATTN=old timeout 200 python bench.py $B 2>> $OUT/ab.err | tail -1) > $OUT/ab_attn_old_$rnd.json
-  (ASYRP_DEEP_RING=0 timeout 200 python bench.py $B 2>> $OUT/ab.err | tail -1) > $OUT/ab_deep_ring_off_$rnd.json
+  (ASYRP_WEIGHT_REGS=0 timeout 200 python bench.py $B 2>> $OUT/ab.err | tail -1) > $OUT/ab_weight_regs_off_$rnd.json
 done
 python - <<PY
 import json, glob
