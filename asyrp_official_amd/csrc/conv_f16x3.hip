@@ -845,14 +845,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //              (py, px), into four taps whose weights are sums of the original ones (built on the host at parameter upload).
 //              One workgroup computes a 16 x 16 patch of SOURCE positions for one phase (17 x 17 halo, 4 taps per chunk) and
 //              scatters to the stride-2 output grid: 4/9 of the matrix work of the 3x3 form, no duplicated halo staging.
-//   BREG_ ("weights through registers"): the small forms (8 x 8 patches, the 128-pixel form, stride 2) issue only 12-24 matrix
-//              instructions per wave and K-step, so their step time is the time the 16 KB weight slice of the NEXT step needs to
-//              arrive -- and LDS-DMA delivers only ~24 GB/s into one CU (MI355X_MICROARCH.md "ldsdma-fill": 0.64 us per 16 KiB;
-//              measured here: 512->512 @8x8 runs at 0.69 us per step for 0.08 us of matrix work, and a deeper LDS-DMA ring made
-//              it 9 % SLOWER, profiles/rd3d_*_NEGATIVE.txt: it is the fill RATE, not its latency).  With BREG the slice travels
-//              global_load_dwordx4 -> registers -> ds_write_b128 (2 x 16 B per thread and step, same LDS image): the ordinary
-//              vector-memory path is not bound by that cadence.  Same products in the same order: bit-identical results.
-template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3, int BREG_ = 0>
+// Measured and NOT kept for the small forms (8 x 8 patches, the 128-pixel form, stride 2: 12-24 matrix instructions per wave and
+// K-step, 0.69 us per step on the 8 x 8 layers for 0.08 us of matrix work), both interleaved on one box at B=32:
+//   * a deeper LDS-DMA weight ring (3-4 slots, inline-asm DMA, hand-counted vmcnt): 8-10 % SLOWER (profiles/rd3d_*_NEGATIVE.txt);
+//   * the weight slices through registers (global_load_dwordx4 -> ds_write_b128, two sets, two steps ahead): 30-45 % SLOWER
+//     (profiles/rd3e_*_NEGATIVE.txt).
+// Neither the latency nor the rate of the LDS-DMA fill is what these steps wait for; the two-slot LDS-DMA loop stays.
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
   static constexpr int KS = KS_, NTAPS = KS * KS;              // 3 x 3 taps, or the 2 x 2 taps of one output phase
@@ -866,7 +865,6 @@ struct K32Cfg {
   static constexpr int NU = NPIX * 2, NA = (NU + NT - 1) / NT;
   static constexpr int NSC = (BM * 4 + NT - 1) / NT;           // shortcut-phase work items per thread
   static constexpr int NPW = 16 / NW;                          // LDS-DMA pieces per wave and step
-  static constexpr int BREG = BREG_;     // 0: LDS-DMA; 2: two register sets, two steps ahead; 1: one set, one step ahead (8 VGPRs)
   static constexpr size_t SMEM = 2 * (size_t)SLOT_BYTES + 2 * (size_t)A_BYTES;
   static constexpr int MINW = (2 * NW) / 4;                    // two workgroups per CU
   static_assert(8 * BM * 16 <= 2 * A_BYTES, "the shortcut phase's 32-channel centre tile lives in the two halo buffers");
@@ -1010,23 +1008,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
-  // BREG: the same pieces through registers (one 16-B global load per lane and piece, written to the slot before the step's barrier)
-  constexpr int BREG = T::BREG;
-  constexpr int NPWE = (NP == 1) ? (8 + T::NW - 1) / T::NW : T::NPW;
-  // two register sets, plain named values (arrays picked by a run-time index end up in scratch): the slice of step s+2 is in
-  // flight while step s computes
-  static_assert(NPWE <= 2, "weight pieces per wave");
-  float4 b00 = make_float4(0.f, 0.f, 0.f, 0.f), b01 = b00, b10 = b00, b11 = b00;
-  auto b_src = [&](int s, int k) {
-    const int pc = wave + k * T::NW;
-    const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
-    return reinterpret_cast<const float4*>(wpk + ((long long)((2 * s + i) * 4 + u) * p.cout_pad + n0 + part * 64 + lane) * 16);
-  };
-  auto b_dst = [&](int slot, int k) {
-    const int pc = wave + k * T::NW;
-    const int i = (NP == 1) ? pc >> 2 : pc >> 3, u = (NP == 1) ? (pc >> 1) & 1 : (pc & 7) >> 1, part = pc & 1;
-    return reinterpret_cast<float4*>(Bs + slot * SLOT_BYTES + i * B_BYTES + (u * BN + part * 64 + lane) * 16);
-  };
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   // row r16 of row block tm = patch pixel ((wm * 4 + tm) * FR + r16 / PW, r16 % PW)
@@ -1042,23 +1023,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
-  static_assert(!(BREG && (SC || ABL)), "the register weight path has no fused-shortcut phase and no ablation switches");
-  if (BREG) {
-    b00 = *b_src(0, 0);
-    if (NPWE > 1) b01 = *b_src(0, 1);
-    *b_dst(0, 0) = b00;
-    if (NPWE > 1) *b_dst(0, 1) = b01;
-  } else {
-    issue_slot(0, 0);
-  }
+  issue_slot(0, 0);
   gload_A(0);
   write_A(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (BREG == 2 && p.Cin / XKC * T::NTAPS / 2 > 1) {   // step 1's slice (set 1): written to slot 1 at the end of step 0
-    b10 = *b_src(1, 0);
-    if (NPWE > 1) b11 = *b_src(1, 1);
-  }
 
   // one K = 32 step: 2 * (4 + TN) fragments, 12 * TN matrix instructions (16 and 48 on the main tile); pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
   // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
@@ -1155,15 +1124,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const int nsteps = nsteps3 + nsc;
   int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
   for (int s = 0; s < nsteps3; ++s) {
-    if (BREG == 2) {                                              // set s&1 held step s's slice, stored a step ago
-      if (s + 2 < nsteps) {
-        if (s & 1) { b10 = *b_src(s + 2, 0); if (NPWE > 1) b11 = *b_src(s + 2, 1); }
-        else { b00 = *b_src(s + 2, 0); if (NPWE > 1) b01 = *b_src(s + 2, 1); }
-      }
-    } else if (BREG == 1) {                                       // one set: the next step's slice travels under this step's passes
-      if (s + 1 < nsteps) { b00 = *b_src(s + 1, 0); if (NPWE > 1) b01 = *b_src(s + 1, 1); }
-    }
-    else if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
+    if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
     const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;   // t / KW
@@ -1183,25 +1144,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       write_A(need, need & 1);
       staged = need;
     }
-    if (BREG == 1) {
-      if (s + 1 < nsteps) { *b_dst((s + 1) & 1, 0) = b00; if (NPWE > 1) *b_dst((s + 1) & 1, 1) = b01; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    } else if (BREG == 2) {
-      // slot (s+1)&1 was last read in step s-1, a barrier ago; its slice was loaded a whole step earlier.  No vmcnt(0) here (the
-      // load of step s+2 stays in flight; hipcc's own counted waits cover the registers it reads) and a raw barrier:
-      // __syncthreads() would drain the vector-memory counter
-      if (s + 1 < nsteps) {
-        if ((s + 1) & 1) { *b_dst(1, 0) = b10; if (NPWE > 1) *b_dst(1, 1) = b11; }
-        else { *b_dst(0, 0) = b00; if (NPWE > 1) *b_dst(0, 1) = b01; }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
   if (SC) {
     const char* const Asc = As + (kq * BM + wm * 64 + r16) * 16;
@@ -1343,21 +1287,6 @@ using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
 using K32Up = K32Cfg<8, 2, 16, 1, 2>;
-using K32HalfR = K32Cfg<8, 4, 16, 1, 3, 2>;     // the register weight path (no fused shortcut)
-using K32Img8R = K32Cfg<8, 8, 8, 1, 3, 2>;
-using K32S2R = K32Cfg<8, 8, 16, 2, 3, 2>;
-using K32MainR = K32Cfg<8, 2, 16, 1, 3, 1>;       // experiment: the main tile with its weights through ONE register set (126 VGPRs)
-// A/B switch: ASYRP_WEIGHT_REGS=0 keeps LDS-DMA for the weights of the 16x16 / 8x8 / stride-2 forms (recorded in bench.py's line)
-// experiment switch (default OFF): ASYRP_MAIN_WEIGHT_REGS=1 runs the plain (no fused shortcut) launches of the main tile with
-// their weights through registers
-static bool main_weight_regs() {
-  static const bool on = [] { const char* e = getenv("ASYRP_MAIN_WEIGHT_REGS"); return e && e[0] == '1'; }();
-  return on;
-}
-static bool weight_regs_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_WEIGHT_REGS"); return !(e && e[0] == '0'); }();
-  return on;
-}
 template <class T, bool SC, bool ABL = false, int NP = 3>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
@@ -1539,10 +1468,7 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
     return launch_x<X256x128w8_3, true, false, false, true, NP>(a, s);
   }
   if (a.ks == 3) {
-    if (a.stride == 2) {
-      if (tile != XT_64x128K32S2) return launch_x<X64x128_3s2, true, false, true, false, NP>(a, s);
-      return weight_regs_enabled() ? launch_k32<K32S2R, false, false, NP>(a, s) : launch_k32<K32S2, false, false, NP>(a, s);
-    }
+    if (a.stride == 2) return tile == XT_64x128K32S2 ? launch_k32<K32S2, false, false, NP>(a, s) : launch_x<X64x128_3s2, true, false, true, false, NP>(a, s);
     switch (tile) {
       case XT_256x128: return launch_x<X256x128_3, true, false, true, false, NP>(a, s);
       case XT_128x128: return launch_x<X128x128_3, true, false, true, false, NP>(a, s);
@@ -1551,9 +1477,9 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
       case XT_256x64: return launch_x<X256x64_3, true, false, true, false, NP>(a, s);
       case XT_256x32: return launch_x<X256x32_3, true, false, true, false, NP>(a, s);
       case XT_256x128W8: return launch_x<X256x128w8_3, true, false, false, false, NP>(a, s);
-      case XT_256x128K32: return main_weight_regs() ? launch_k32<K32MainR, false, false, NP>(a, s) : launch_k32<K32Main, false, false, NP>(a, s);
-      case XT_128x128K32: return weight_regs_enabled() ? launch_k32<K32HalfR, false, false, NP>(a, s) : launch_k32<K32Half, false, false, NP>(a, s);
-      case XT_64x128K32: return weight_regs_enabled() ? launch_k32<K32Img8R, false, false, NP>(a, s) : launch_k32<K32Img8, false, false, NP>(a, s);
+      case XT_256x128K32: return launch_k32<K32Main, false, false, NP>(a, s);
+      case XT_128x128K32: return launch_k32<K32Half, false, false, NP>(a, s);
+      case XT_64x128K32: return launch_k32<K32Img8, false, false, NP>(a, s);
     }
   } else {
     switch (tile) {

@@ -95,8 +95,8 @@ if __name__ == "__main__":
                 print(f"  {math:5s} {Ch}->{Ch} @{H}->{2 * H} prologue={pro}: " + "  ".join(f"t{t} {med[t]:7.1f} us" for t in tiles) +
                       f"   ratio {med[11] / med[0]:.3f}", flush=True)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[2] == "small":     # the 16x16 / 8x8 layers on the launcher's own choice; run once per ASYRP_WEIGHT_REGS value
-        print(f"-- B={B}, ASYRP_WEIGHT_REGS={os.environ.get('ASYRP_WEIGHT_REGS', 'default')}: us per launch, TFLOP/s (median of 5 x 10 launches)")
+    if len(sys.argv) > 2 and sys.argv[2] == "small":     # the 16x16 / 8x8 layers on the launcher's own choice; used for the A/Bs recorded under profiles/rd3d_*, rd3e_*
+        print(f"-- B={B}, launcher's choice: us per launch, TFLOP/s (median of 5 x 10 launches)")
         for math in ("f16x3", "f16"):
             for (H, Ch, C1, Co, kw) in ((8, 512, 0, 512, {}), (8, 512, 0, 512, dict(res=1)), (16, 512, 0, 512, {}), (16, 512, 512, 512, {}),
                                         (16, 256, 0, 512, {}), (16, 512, 0, 512, dict(res=1))):
