@@ -311,11 +311,25 @@ hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-template <int NKTW /* 16-key tiles per wave */, int NP>
+// phase stamps (profiling library only, -DASYRP_BENCH_HOOKS): wave 0 of every workgroup records s_memrealtime (100 MHz) at the
+// phase boundaries into AttnArgs::dbg [workgroup][8]; scripts/attn_phases.py prints the breakdown
+#ifdef ASYRP_BENCH_HOOKS
+#define ATTN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
+// DK: channel steps in flight in phase 1 (divides Dh/32); JC: output items a wave runs side by side in phase 2 (= items per
+// wave, Dh/64, at least 1).  Both are template parameters so that EVERY path through the loops issues the same number of
+// loads: hipcc's waitcnt pass then emits exact counted waits.  With loads under run-time conditions it falls back to vmcnt(0)
+// before every use and the prefetch rings collapse to one exposed round trip per step -- measured with the phase stamps of the
+// profiling library: 15 us (phase 1) + 21 us (phase 2) of a 49 us workgroup life (profiles/rd3g_*).
+template <int NKTW /* 16-key tiles per wave */, int NP, int DK, int JC>
 __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ATTN_STAMP(0);
   const int T = p.T, Dh = p.Dh, ld = p.ld16;
   const int nks = Dh >> 5, nsteps = T >> 5;       // 32-channel steps of Q K^T, 32-key steps of P V
   // Workgroups go to the 8 XCDs round-robin by linear id: with the identity map the 8 query blocks of one (image, head) land on 8
@@ -364,6 +378,7 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     }
   }
   __syncthreads();
+  ATTN_STAMP(1);
 
   // ---- phase 1: S^T = K Q^T, this wave's key tiles ----
   f32x4 s[NKTW][2];
@@ -384,7 +399,6 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   if (kval[0]) {
     // the K rows of the next DK channel steps are in flight while a step feeds the matrix cores: the kernel is bound by the
     // round trips of these loads (one workgroup per CU, two waves per SIMD), so the ring is as deep as the registers allow
-    constexpr int DK = (NKTW <= 2) ? 4 : 2;
     h8 kh[DK][NKTW], kl[DK][NKTW];
     auto loadK = [&](int ks, int buf) {
 #pragma unroll
@@ -394,35 +408,37 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
       }
     };
 #pragma unroll
-    for (int u = 0; u < DK; ++u)
-      if (u < nks) loadK(u, u);
+    for (int u = 0; u < DK; ++u) loadK(u, u);                      // nks % DK == 0 (launcher)
+    // (scheduling barriers pin the loads where they are written: left alone, the machine scheduler sinks every load next to
+    // its use to save registers, which is exactly the exposed round trip per step the ring exists to avoid)
+    __builtin_amdgcn_sched_barrier(0);
     for (int ks = 0; ks < nks; ks += DK) {
 #pragma unroll
       for (int u = 0; u < DK; ++u) {
         const int k1 = ks + u;
-        if (k1 < nks) {
-          h8 qh[2], ql[2];
+        h8 qh[2], ql[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          qh[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)(k1 * 4 + g) * 32 + qt * 16 + r16) * 16);
+          if (NP == 3) ql[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)((nks + k1) * 4 + g) * 32 + qt * 16 + r16) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NKTW; ++i) {
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            qh[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)(k1 * 4 + g) * 32 + qt * 16 + r16) * 16);
-            if (NP == 3) ql[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)((nks + k1) * 4 + g) * 32 + qt * 16 + r16) * 16);
+            if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[u][i], qh[qt], s[i][qt], 0, 0, 0);
+            s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], qh[qt], s[i][qt], 0, 0, 0);
+            if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], ql[qt], s[i][qt], 0, 0, 0);
           }
-#pragma unroll
-          for (int i = 0; i < NKTW; ++i) {
-            if (!kval[i]) continue;
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-              if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[u][i], qh[qt], s[i][qt], 0, 0, 0);
-              s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], qh[qt], s[i][qt], 0, 0, 0);
-              if (NP == 3) s[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u][i], ql[qt], s[i][qt], 0, 0, 0);
-            }
-          }
-          if (k1 + DK < nks) loadK(k1 + DK, u);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        loadK(min(k1 + DK, nks - 1), u);      // unconditional (the tail re-reads the last step): static load counts
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
+  ATTN_STAMP(2);
   // ---- softmax over the keys of query (q0 + qt*16 + r16): accumulator element r of tile i is key (wave + 8i)*16 + 4g + r ----
   float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -491,94 +507,115 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     }
   }
   __syncthreads();
+  ATTN_STAMP(3);
 
   // ---- phase 2: O^T = V^T P^T; items (16-channel tile dt, query tile qt): wave w owns the items w, w+8, ... -- all of query
   // tile w & 1, channel tiles (w >> 1) + 4j -- and runs up to JC of them side by side: one P fragment per key step feeds JC
   // accumulators, and the V^T rows of the next step are in flight meanwhile ----
-  constexpr int JC = 8;
   const int nitems = (Dh >> 4) * 2;
-  const int nj = (nitems - wave + 7) >> 3;           // items of this wave (wave-uniform)
+  const int nj = (nitems - wave + 7) >> 3;           // items of this wave (wave-uniform): JC, or 0 for the waves beyond the items
   const int qt = wave & 1, dtb = wave >> 1;
   float* __restrict__ outz = p.out + (long long)b * p.o_img_stride + (long long)head * p.o_head_stride;
   const char* pb = Ps + ((size_t)(qt * nsteps * 4 + g) * 16 + r16) * 16;
   const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
-  for (int j0 = 0; j0 < nj; j0 += JC) {
+  if (nj > 0) {
     f32x4 o[JC];
     int voff[JC];
 #pragma unroll
     for (int jj = 0; jj < JC; ++jj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[jj][r] = 0.f;
-      const int dt = dtb + 4 * min(j0 + jj, nj - 1);
-      voff[jj] = (dt * 16 + r16) * T + g * 8;        // (a head's V^T slab is far below 2^31 halfs)
+      voff[jj] = ((dtb + 4 * jj) * 16 + r16) * T + g * 8;        // (a head's V^T slab is far below 2^31 halfs)
     }
     h8 vh[2][JC], vl[2][JC];
     auto loadV = [&](int st, int buf) {
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
-        if (j0 + jj < nj) {
-          vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 32);
-          if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 32);
-        }
+        vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 32);
+        if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 32);
       }
     };
     loadV(0, 0);
-    for (int st = 0; st < nsteps; st += 2) {
+    loadV(min(1, nsteps - 1), 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int st = 0; st < nsteps; st += 2) {          // nsteps is even or 1 (T % 64 == 0 or T == 32: launcher)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int s1 = st + u;
-        if (s1 < nsteps) {
-          if (s1 + 1 < nsteps) loadV(s1 + 1, u ^ 1);
+        if (s1 < nsteps) {                            // (only false for u = 1 when nsteps == 1: wave-uniform, loads below unaffected)
           const h8 ph = *reinterpret_cast<const h8*>(pb + (size_t)s1 * 4 * 16 * 16);
           h8 pl;
           if (NP == 3) pl = *reinterpret_cast<const h8*>(pb + (size_t)s1 * 4 * 16 * 16 + plo);
 #pragma unroll
           for (int jj = 0; jj < JC; ++jj) {
-            if (j0 + jj < nj) {
-              if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[u][jj], ph, o[jj], 0, 0, 0);
-              o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], ph, o[jj], 0, 0, 0);
-              if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], pl, o[jj], 0, 0, 0);
-            }
+            if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[u][jj], ph, o[jj], 0, 0, 0);
+            o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], ph, o[jj], 0, 0, 0);
+            if (NP == 3) o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[u][jj], pl, o[jj], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        loadV(min(s1 + 2, nsteps - 1), u);            // two key steps ahead, unconditional
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    ATTN_STAMP(4);
     // accumulator: column = query r16 of the tile, rows = channels 4g .. 4g+3 of the tile: 16 contiguous bytes of out[q][.]
     const int q = q0 + qt * 16 + r16;
+    if (q < T) {
 #pragma unroll
-    for (int jj = 0; jj < JC; ++jj) {
-      if (j0 + jj < nj && q < T) {
-        const int dt = dtb + 4 * (j0 + jj);
+      for (int jj = 0; jj < JC; ++jj) {
         float4 v = make_float4(o[jj][0] * P_UNSCALE, o[jj][1] * P_UNSCALE, o[jj][2] * P_UNSCALE, o[jj][3] * P_UNSCALE);
-        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + dt * 16 + 4 * g) = v;
+        *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + (dtb + 4 * jj) * 16 + 4 * g) = v;
       }
     }
   }
+  ATTN_STAMP(5);
 }
 
 static size_t attn_planes_smem(int T, int Dh) {
   return (size_t)2 * (Dh >> 5) * 4 * 32 * 16 + (size_t)2 * 2 * (T >> 5) * 4 * 16 * 16 + 2 * 8 * 32 * sizeof(float);
 }
 
-bool attn_planes_supported(int T, int Dh) {
-  return T >= 32 && T <= 1024 && (T & 31) == 0 && Dh >= 32 && Dh <= 512 && (Dh & 31) == 0 && attn_planes_smem(T, Dh) <= 160 * 1024;
-}
-
-template <int NKTW, int NP>
+template <int NKTW, int NP, int DK, int JC>
 static hipError_t launch_attn_planes_t(const AttnArgs& a, hipStream_t s) {
   const size_t smem = attn_planes_smem(a.T, a.Dh);
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_planes_kernel<NKTW, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_planes_kernel<NKTW, NP, DK, JC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   dim3 grid(a.T / 32, a.heads, a.B);
-  hipLaunchKernelGGL((attn_planes_kernel<NKTW, NP>), grid, dim3(512), smem, s, a);
+  hipLaunchKernelGGL((attn_planes_kernel<NKTW, NP, DK, JC>), grid, dim3(512), smem, s, a);
   return hipGetLastError();
+}
+
+// the shapes the reference's configurations produce: single 512- / 64-wide head at T = 256 / 64 (DDPM), 64-wide heads at
+// T = 1024 / 256 / 64 (iDDPM, ADM); other supported shapes fall back to attn_f16x3_kernel (attn_planes_supported)
+template <int NP>
+static hipError_t launch_attn_planes_np(const AttnArgs& a, hipStream_t s) {
+  const int nkt = (a.T / 16 + 7) / 8;               // 16-key tiles per wave
+  if (a.Dh == 512) {                                // nks = 16, 8 items per wave
+    if (nkt <= 1) return launch_attn_planes_t<1, NP, 4, 8>(a, s);
+    if (nkt <= 2) return launch_attn_planes_t<2, NP, 4, 8>(a, s);
+    return hipErrorInvalidValue;
+  }
+  if (a.Dh == 64) {                                 // nks = 2, 1 item per wave
+    if (nkt <= 1) return launch_attn_planes_t<1, NP, 2, 1>(a, s);
+    if (nkt <= 2) return launch_attn_planes_t<2, NP, 2, 1>(a, s);
+    if (nkt <= 4) return launch_attn_planes_t<4, NP, 2, 1>(a, s);
+    return launch_attn_planes_t<8, NP, 2, 1>(a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+bool attn_planes_supported(int T, int Dh) {
+  if (!(T >= 32 && T <= 1024 && (T == 32 || (T & 63) == 0) && attn_planes_smem(T, Dh) <= 160 * 1024)) return false;
+  if (Dh == 512) return T <= 256;
+  return Dh == 64;
 }
 
 hipError_t launch_attention_planes(const AttnArgs& a, hipStream_t s) {
@@ -586,12 +623,7 @@ hipError_t launch_attention_planes(const AttnArgs& a, hipStream_t s) {
   if ((a.ld16 & 7) || (a.q_off & 7) || (a.k_off & 7) || (a.head_stride & 7) || (a.ldo & 3) || (a.o_head_stride & 3) ||
       ((uintptr_t)a.qkh & 15) || ((uintptr_t)a.vth & 15) || ((uintptr_t)a.out & 15))
     return hipErrorInvalidValue;
-  const int nkt = (a.T / 16 + 7) / 8;               // 16-key tiles per wave
-  const bool one = (a.np == 1);
-  if (nkt <= 1) return one ? launch_attn_planes_t<1, 1>(a, s) : launch_attn_planes_t<1, 3>(a, s);
-  if (nkt <= 2) return one ? launch_attn_planes_t<2, 1>(a, s) : launch_attn_planes_t<2, 3>(a, s);
-  if (nkt <= 4) return one ? launch_attn_planes_t<4, 1>(a, s) : launch_attn_planes_t<4, 3>(a, s);
-  return one ? launch_attn_planes_t<8, 1>(a, s) : launch_attn_planes_t<8, 3>(a, s);
+  return a.np == 1 ? launch_attn_planes_np<1>(a, s) : launch_attn_planes_np<3>(a, s);
 }
 
 // fp32 q|k|v rows -> the split planes (what the projection's epilogue writes in the engine); one thread per element

@@ -2941,6 +2941,45 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
 }
 #endif
 
+#ifdef ASYRP_BENCH_HOOKS
+// profiling library only: run attn_planes_kernel `iters` times on synthetic planes and return (a) the average launch time (HIP
+// events) and (b) the phase stamps of the last launch, [B*heads*T/32 workgroups][8] s_memrealtime ticks (100 MHz)
+int asyrp_op_attention_phases(int device, int B, int C, int T, int heads, int np, int iters, float* ms_out,
+                              unsigned long long* stamps_host, void* stream) {
+  const int Dh = C / heads;
+  if (!attn_planes_supported(T, Dh) || iters < 1) return fail(ASYRP_EINVAL, "shape not covered");
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nqk = (size_t)B * T * 3 * C, nv = (size_t)B * C * T, nwg = (size_t)B * heads * (T / 32);
+  float* qkv = nullptr; _Float16 *h, *l, *vh, *vl; float* out; unsigned long long* dbg;
+  HIPCHK(hipMalloc(&qkv, nqk * 4)); HIPCHK(hipMalloc(&h, nqk * 2)); HIPCHK(hipMalloc(&l, nqk * 2));
+  HIPCHK(hipMalloc(&vh, nv * 2)); HIPCHK(hipMalloc(&vl, nv * 2)); HIPCHK(hipMalloc(&out, nv * 4)); HIPCHK(hipMalloc(&dbg, nwg * 64));
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, qkv, (long long)nqk, 7u, 2.0f);
+  HIPCHK(launch_qkv_to_planes(qkv, 3 * C, B, T, 3 * C, heads == 1 ? 3 * C : 3 * Dh, heads == 1 ? 2 * C : 2 * Dh, heads == 1 ? C : Dh, h, l, vh, vl, s));
+  AttnArgs a;
+  memset(&a, 0, sizeof a);
+  a.qkh = h; a.qkl = l; a.vth = vh; a.vtl = vl; a.ld16 = 3 * C;
+  a.head_stride = (heads == 1) ? 0 : 3 * Dh; a.q_off = 0; a.k_off = (heads == 1) ? C : Dh;
+  a.B = B; a.heads = heads; a.T = T; a.Dh = Dh; a.scale = 1.0f / std::sqrt((float)Dh);
+  a.out = out; a.ldo = C; a.o_img_stride = (long long)T * C; a.o_head_stride = Dh; a.np = np; a.dbg = dbg;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  hipError_t le = launch_attention_planes(a, s);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_attention_planes(a, s);
+  (void)hipEventRecord(e1, s);
+  hipError_t se = hipStreamSynchronize(s);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (stamps_host) (void)hipMemcpy(stamps_host, dbg, nwg * 64, hipMemcpyDeviceToHost);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(qkv); (void)hipFree(h); (void)hipFree(l); (void)hipFree(vh); (void)hipFree(vl); (void)hipFree(out); (void)hipFree(dbg);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "attention phases run failed");
+  *ms_out = ms / iters;
+  return 0;
+}
+#endif
+
 int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int heads, int fused, float* out, void* stream) {
   if (!qkv || !out || B < 1 || heads < 1 || C % heads) return fail(ASYRP_EINVAL, "bad argument");
   if (fused && !attn_fused_supported(T, C / heads, 3 * C, C)) return fail(ASYRP_EINVAL, "shape not covered by the fused attention kernel");

@@ -144,6 +144,7 @@ struct AttnArgs {
   // attn_planes_kernel: q|k as f16 hi/lo planes [B][T][ld16] (element (b, t, c) of q at b*T*ld16 + head*head_stride + q_off + t*ld16 + c,
   // all in halfs) and v transposed, [B][heads*Dh][T]; written by the q|k|v projection's epilogue (GemmArgs::o16h ...)
   const _Float16* qkh; const _Float16* qkl; const _Float16* vth; const _Float16* vtl; int ld16;
+  unsigned long long* dbg;        // profiling library only: phase stamps [workgroup][8] (null in the product)
 };
 bool attn_fused_supported(int T, int Dh, int ld, int ldo);
 hipError_t launch_attention_fused(const AttnArgs& a, hipStream_t s);

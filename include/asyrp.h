@@ -287,6 +287,11 @@ int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int he
 int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
                         void* stream);
+/* attn_planes_kernel on synthetic planes: average launch time over `iters` launches and the phase stamps of the last one,
+ * stamps_host [B*heads*T/32][8] s_memrealtime ticks (100 MHz): 0 start, 1 Q staged, 2 S^T done, 3 P in LDS, 4 last PV item done,
+ * 5 end (scripts/attn_phases.py). */
+int asyrp_op_attention_phases(int device, int B, int C, int T, int heads, int np, int iters, float* ms_out,
+                              unsigned long long* stamps_host, void* stream);
 #endif
 
 #ifdef __cplusplus
