@@ -341,39 +341,41 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   if ((nblk & 7) == 0) w = (w & 7) * (nblk >> 3) + (w >> 3);
   const int qb = w % (int)gridDim.x, hb = w / (int)gridDim.x;
   const int q0 = qb * 32, head = hb % (int)gridDim.y, b = hb / (int)gridDim.y;
-  const long long qk_base = (long long)b * T * ld + (long long)head * p.head_stride;
-  const _Float16* __restrict__ QH = p.qkh + qk_base + p.q_off;
-  const _Float16* __restrict__ QL = p.qkl + qk_base + p.q_off;
-  const _Float16* __restrict__ KH = p.qkh + qk_base + p.k_off;
-  const _Float16* __restrict__ KL = p.qkl + qk_base + p.k_off;
-  const long long vt_base = ((long long)b * p.heads + head) * Dh * T;
-  const _Float16* __restrict__ VH = p.vth + vt_base;
-  const _Float16* __restrict__ VL = p.vtl + vt_base;
+  // fragment-major planes (kernels.h frag_off): the 1-KiB block of (16-token tile tt, 32-channel step cs) of the q|k planes sits at
+  // ((tt * ld/32 + cs) * 64 + lane) * 8 halfs; q starts at channel step (head*head_stride + q_off)/32, k likewise
+  const long long img = (long long)b * T * ld;
+  const int ldb = ld >> 5;
+  const int qcs = ((int)(head * p.head_stride) + p.q_off) >> 5, kcs = ((int)(head * p.head_stride) + p.k_off) >> 5;
+  const _Float16* __restrict__ PH = p.qkh + img;
+  const _Float16* __restrict__ PL = p.qkl + img;
+  // v^T planes: rows = this image's v channels (head*Dh + d), cols = tokens: block (dt, st) at ((dt * T/32 + st) * 64 + lane) * 8
+  const long long vimg = (long long)b * p.heads * Dh * T;
+  const _Float16* __restrict__ VH = p.vth + vimg;
+  const _Float16* __restrict__ VL = p.vtl + vimg;
+  const int vdt0 = (head * Dh) >> 4;
 
-  // LDS: Qs [plane][ks][kq][32 q][8 halfs] | Ps [plane][qt][step][kq][16 q][8 halfs] | red [2][8 waves][32]
+  // LDS: Qs [plane][ks][query tile][lane][8 halfs] | Ps [plane][qt][step][kq][16 q][8 halfs] | red [2][8 waves][32]
   char* const Qs = smem;
   char* const Ps = smem + (size_t)2 * nks * 4 * 32 * 16;
   float* const red = reinterpret_cast<float*>(Ps + (size_t)2 * 2 * nsteps * 4 * 16 * 16);
 
-  // ---- stage Q: one 16-B copy per (plane, ks, kq, q) ----
+  // ---- stage Q: [plane][ks][query tile] blocks of 1 KiB, copied as they are (lane-linear) ----
   {
-    const int nq = (NP == 1 ? 1 : 2) * nks * 4 * 32;
+    const int nq = (NP == 1 ? 1 : 2) * nks * 2 * 64;   // 16-B pieces
+    const int qt0 = q0 >> 4;
     for (int i0 = tid; i0 < nq; i0 += 4 * 512) {     // four 16-B loads in flight per thread, then the four LDS writes
       h8 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = min(i0 + u * 512, nq - 1);
-        const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
-        const int row = min(q0 + q, T - 1);
-        v[u] = *reinterpret_cast<const h8*>((pl ? QL : QH) + (long long)row * ld + ks * 32 + kq * 8);
+        const int ln = i & 63, qt = (i >> 6) & 1, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
+        const int tt = min(qt0 + qt, (T >> 4) - 1);
+        v[u] = *reinterpret_cast<const h8*>((pl ? PL : PH) + ((long long)(tt * ldb + qcs + ks) * 64 + ln) * 8);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * 512;
-        if (i < nq) {
-          const int q = i & 31, kq = (i >> 5) & 3, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
-          *reinterpret_cast<h8*>(Qs + ((size_t)((pl * nks + ks) * 4 + kq) * 32 + q) * 16) = v[u];
-        }
+        if (i < nq) *reinterpret_cast<h8*>(Qs + (size_t)i * 16) = v[u];
       }
     }
   }
@@ -388,13 +390,13 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[i][qt][r] = 0.f;
-  int koff[NKTW];
+  long long koff[NKTW];
   bool kval[NKTW];
 #pragma unroll
   for (int i = 0; i < NKTW; ++i) {
     const int kt = wave + 8 * i;
     kval[i] = (kt * 16 < T);                          // wave-uniform (T % 16 == 0)
-    koff[i] = min(kt * 16 + r16, T - 1) * ld + g * 8;
+    koff[i] = ((long long)(min(kt, (T >> 4) - 1) * ldb + kcs) * 64 + lane) * 8;     // + ks * 512 halfs per channel step
   }
   if (kval[0]) {
     // the K rows of the next DK channel steps are in flight while a step feeds the matrix cores: the kernel is bound by the
@@ -403,8 +405,8 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     auto loadK = [&](int ks, int buf) {
 #pragma unroll
       for (int i = 0; i < NKTW; ++i) {
-        kh[buf][i] = *reinterpret_cast<const h8*>(KH + koff[i] + ks * 32);
-        if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(KL + koff[i] + ks * 32);
+        kh[buf][i] = *reinterpret_cast<const h8*>(PH + koff[i] + ks * 512);
+        if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(PL + koff[i] + ks * 512);
       }
     };
 #pragma unroll
@@ -419,8 +421,8 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
         h8 qh[2], ql[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          qh[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)(k1 * 4 + g) * 32 + qt * 16 + r16) * 16);
-          if (NP == 3) ql[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)((nks + k1) * 4 + g) * 32 + qt * 16 + r16) * 16);
+          qh[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)(k1 * 2 + qt) * 64 + lane) * 16);
+          if (NP == 3) ql[qt] = *reinterpret_cast<const h8*>(Qs + ((size_t)((nks + k1) * 2 + qt) * 64 + lane) * 16);
         }
 #pragma unroll
         for (int i = 0; i < NKTW; ++i) {
@@ -525,14 +527,14 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     for (int jj = 0; jj < JC; ++jj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[jj][r] = 0.f;
-      voff[jj] = ((dtb + 4 * jj) * 16 + r16) * T + g * 8;        // (a head's V^T slab is far below 2^31 halfs)
+      voff[jj] = ((vdt0 + dtb + 4 * jj) * nsteps * 64 + lane) * 8;   // + st * 512 halfs per key step (an image's V^T is far below 2^31 halfs)
     }
     h8 vh[2][JC], vl[2][JC];
     auto loadV = [&](int st, int buf) {
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
-        vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 32);
-        if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 32);
+        vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 512);
+        if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 512);
       }
     };
     loadV(0, 0);
@@ -620,7 +622,7 @@ bool attn_planes_supported(int T, int Dh) {
 
 hipError_t launch_attention_planes(const AttnArgs& a, hipStream_t s) {
   if (!attn_planes_supported(a.T, a.Dh) || !a.qkh || !a.vth || (a.np != 1 && (!a.qkl || !a.vtl))) return hipErrorInvalidValue;
-  if ((a.ld16 & 7) || (a.q_off & 7) || (a.k_off & 7) || (a.head_stride & 7) || (a.ldo & 3) || (a.o_head_stride & 3) ||
+  if ((a.ld16 & 31) || (a.q_off & 31) || (a.k_off & 31) || (a.head_stride & 31) || (a.ldo & 3) || (a.o_head_stride & 3) ||
       ((uintptr_t)a.qkh & 15) || ((uintptr_t)a.vth & 15) || ((uintptr_t)a.out & 15))
     return hipErrorInvalidValue;
   return a.np == 1 ? launch_attn_planes_np<1>(a, s) : launch_attn_planes_np<3>(a, s);
@@ -639,13 +641,14 @@ __global__ void qkv_to_planes_kernel(const float* __restrict__ qkv, int ld, int 
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     const int nm = n % v_mod;
-    if (nm >= v_off) {
-      const long long o = (b * Cv + (n / v_mod) * v_dh + nm - v_off) * T + t;
+    if (nm >= v_off) {      // fragment-major (kernels.h frag_off): rows = v channels, cols = tokens
+      const long long o = b * Cv * T + frag_off((n / v_mod) * v_dh + nm - v_off, t, T);
       vth[o] = h;
       vtl[o] = l;
-    } else {
-      o16h[bt * C3 + n] = h;
-      o16l[bt * C3 + n] = l;
+    } else {                // rows = tokens, cols = the 3C channels
+      const long long o = b * (long long)T * C3 + frag_off(t, n, C3);
+      o16h[o] = h;
+      o16l[o] = l;
     }
   }
 }

@@ -634,7 +634,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
   };
   if (KS == 1 && p.o16h) {
     // split-plane output (the q|k|v projection of an attention block, GemmArgs::o16h): every value leaves as an exact two-term
-    // f16 split; q and k rows into [pixel][ld16] planes, the v channels transposed into [channel][pixel] planes.  Accumulator
+    // f16 split; q and k rows into [pixel][ld16] planes, the v channels transposed into [channel][pixel] planes, both in the
+    // fragment-major tile order of kernels.h frag_off (pixels % 16 == 0, ld16 % 32 == 0: the launcher of the planes path).  Accumulator
     // elements 4j .. 4j+3 of a lane are 4 consecutive pixels of one channel: one 8-byte store per plane in the transposed part.
     _Float16* __restrict__ oh = p.o16h + (long long)zo * p.o16_zo;
     _Float16* __restrict__ ol = p.o16l + (long long)zo * p.o16_zo;
@@ -647,7 +648,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
       const float add = (has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f);
       const int nm = n % p.v_mod;
       const bool isv = nm >= p.v_off;
-      const long long vrow = (long long)((n / p.v_mod) * p.v_dh + nm - p.v_off) * HWo;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -663,20 +663,24 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
             lo[q] = (_Float16)(v - (float)hh);
           }
           if (isv) {
+            // v^T plane, fragment-major (kernels.h frag_off): 4 consecutive tokens of one channel = 4 consecutive halfs
+            const int vc = (n / p.v_mod) * p.v_dh + nm - p.v_off;
             if (pix + 3 < HWo) {
-              *reinterpret_cast<h4v*>(vh + vrow + pix) = hi;
-              if (vl) *reinterpret_cast<h4v*>(vl + vrow + pix) = lo;
+              const long long o = frag_off(vc, pix, HWo);
+              *reinterpret_cast<h4v*>(vh + o) = hi;
+              if (vl) *reinterpret_cast<h4v*>(vl + o) = lo;
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q)
-                if (pix + q < HWo) { vh[vrow + pix + q] = hi[q]; if (vl) vl[vrow + pix + q] = lo[q]; }
+                if (pix + q < HWo) { const long long o = frag_off(vc, pix + q, HWo); vh[o] = hi[q]; if (vl) vl[o] = lo[q]; }
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               if (pix + q < HWo) {
-                oh[(long long)(pix + q) * p.ld16 + n] = hi[q];
-                if (ol) ol[(long long)(pix + q) * p.ld16 + n] = lo[q];
+                const long long o = frag_off(pix + q, n, p.ld16);
+                oh[o] = hi[q];
+                if (ol) ol[o] = lo[q];
               }
           }
         }

@@ -133,6 +133,16 @@ hipError_t launch_gn_finalize2(const GnFin2Args& a, hipStream_t s);
 
 hipError_t launch_softmax_rows(float* x, long long rows, int T, hipStream_t s);
 
+// Fragment-major layout of the attention planes: every 16-row x 32-column tile of a (rows x cols) f16 matrix is stored as the
+// 1 KiB block one v_mfma_f32_16x16x32_f16 operand fetch reads -- [lane = (col % 32) / 8 * 16 + row % 16][col % 8] -- tiles
+// row-major over (row / 16, col / 32).  A wave's operand load is then ONE fully coalesced 1-KiB access instead of 16 strided
+// 64-byte segments (measured: the strided form held the attention kernel at ~23 GB/s of loads per CU, profiles/rd3h_*).
+//   q|k planes: rows = tokens, cols = the 3C channels of the q|k|v rows (cols_per_row = ld16);  v^T planes: rows = v channels,
+//   cols = tokens (cols_per_row = T).  rows % 16 == 0 and cols % 32 == 0.
+__host__ __device__ inline long long frag_off(int row, int col, int cols_per_row) {
+  return ((long long)((row >> 4) * (cols_per_row >> 5) + (col >> 5)) * 64 + ((col & 31) >> 3) * 16 + (row & 15)) * 8 + (col & 7);
+}
+
 // Fused attention (attention.hip): out[b][t][head*Dh + d] = sum_k softmax_k(scale * q_t.k_k) v_k[d], f16x3 matrix products.
 // qkv rows are tokens: element (b, t, .) at qkv + b*img_stride + head*head_stride + {q,k,v}_off + t*ld (+ channel).
 struct AttnArgs {

@@ -12,7 +12,7 @@ from asyrp_official_amd import _lib
 
 lib = _lib.load_bench()
 NAMES = ["Q staging", "S^T = K Q^T", "softmax + P -> LDS", "O^T = V^T P^T (last item group)", "store / end"]
-for (B, Cc, T, heads, np_) in ((32, 512, 256, 1, 3), (1, 512, 256, 1, 3), (32, 512, 64, 1, 3), (16, 512, 1024, 8, 3), (32, 512, 256, 1, 1)):
+for (B, Cc, T, heads, np_) in ((32, 512, 256, 1, 3), (1, 512, 256, 1, 3), (32, 512, 64, 1, 3), (16, 512, 1024, 8, 3), (64, 512, 256, 8, 3), (32, 512, 256, 1, 1)):
     nwg = B * heads * (T // 32)
     st = np.zeros((nwg, 8), dtype=np.uint64)
     ms = C.c_float()

@@ -418,13 +418,14 @@ def _attention_ref(qkv, B, C, T, heads):
     return torch.einsum("bts,bcs->bct", F.softmax(w, dim=-1), v).reshape(B, -1, T).float()
 
 
-@pytest.mark.parametrize("B,C,T,heads", [(2, 512, 256, 1), (2, 128, 64, 1), (3, 64, 256, 1), (1, 512, 1024, 8), (2, 256, 256, 4),
-                                         (1, 1024, 64, 16), (2, 512, 512, 8), (1, 96, 32, 3)])
+@pytest.mark.parametrize("B,C,T,heads", [(2, 512, 256, 1), (2, 512, 64, 1), (3, 64, 256, 1), (1, 512, 1024, 8), (2, 256, 256, 4),
+                                         (1, 1024, 64, 16), (2, 512, 512, 8), (1, 192, 32, 3), (1, 64, 128, 1)])
 @pytest.mark.parametrize("fused", [3, 4])
 def test_attention_split_plane_kernel(B, C, T, heads, fused):
-    """attn_planes_kernel (csrc/attention.hip; the engine's attention since round 3): q, k as f16 hi/lo planes, v transposed, both
-    layouts (DDPM q|k|v blocks, legacy per-head [q|k|v]), every key-tile instantiation (T = 32 ... 1024), 1 to 16 heads.
-    fused = 3: the fp32-equivalent three-product form at the parity tolerance; 4: the single-product fast mode at its own."""
+    """attn_planes_kernel (csrc/attention.hip; the engine's attention since round 3 for the head shapes of the reference's
+    configurations: one 512-wide head at T <= 256, 64-wide heads at T <= 1024): q, k as fragment-major f16 hi/lo planes, v
+    transposed, both layouts (DDPM q|k|v blocks, legacy per-head [q|k|v]), every key-tile instantiation (T = 32 ... 1024), 1 to
+    16 heads.  fused = 3: the fp32-equivalent three-product form at the parity tolerance; 4: the single-product fast mode."""
     from asyrp_official_amd import _lib
     lib = _lib.load()
     qkv = hash_normal(f"att2.{B}.{C}.{T}.{heads}", (B, 3 * C, T))
@@ -438,3 +439,14 @@ def test_attention_split_plane_kernel(B, C, T, heads, fused):
     else:
         err, scale = float((out.cpu() - ref).abs().max()), float(ref.abs().max())
         assert 1e-7 * scale < err <= 4e-3 * scale, (err, scale)
+
+
+def test_attention_split_plane_kernel_refuses_other_shapes():
+    """Head widths other than 64 / 512 (and ragged T) stay on attn_f16x3_kernel: the hook says so instead of computing garbage."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    for (B, C, T, heads) in ((1, 128, 64, 1), (1, 96, 32, 3), (1, 64, 80, 1), (1, 512, 512, 1)):
+        qd = torch.zeros((B, 3 * C, T), device="cuda")
+        out = torch.empty((B, C, T), device="cuda")
+        with pytest.raises(_lib.AsyrpError, match="not covered"):
+            _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, 3, _p(out), None))
