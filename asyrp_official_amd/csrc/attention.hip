@@ -359,6 +359,31 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   char* const Ps = smem + (size_t)2 * nks * 4 * 32 * 16;
   float* const red = reinterpret_cast<float*>(Ps + (size_t)2 * 2 * nsteps * 4 * 16 * 16);
 
+  // ---- the first DK channel steps of this wave's K tiles go out before anything else: they fly while Q is staged ----
+  long long koff[NKTW];
+  bool kval[NKTW];
+#pragma unroll
+  for (int i = 0; i < NKTW; ++i) {
+    const int kt = wave + 8 * i;
+    kval[i] = (kt * 16 < T);                          // wave-uniform (T % 16 == 0); tiles past T read clamped rows, masked below
+    koff[i] = ((long long)(min(kt, (T >> 4) - 1) * ldb + kcs) * 64 + lane) * 8;     // + ks * 512 halfs per channel step
+  }
+  // the K rows of the next DK channel steps are in flight while a step feeds the matrix cores: the kernel is bound by the
+  // round trips of these loads (one workgroup per CU, two waves per SIMD), so the ring is as deep as the registers allow
+  h8 kh[DK][NKTW], kl[DK][NKTW];
+  auto loadK = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < NKTW; ++i) {
+      kh[buf][i] = *reinterpret_cast<const h8*>(PH + koff[i] + ks * 512);
+      if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(PL + koff[i] + ks * 512);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < DK; ++u) loadK(u, u);                      // nks % DK == 0 (launcher)
+  // (scheduling barriers pin the loads where they are written: left alone, the machine scheduler sinks every load next to
+  // its use to save registers, which is exactly the exposed round trip per step the ring exists to avoid)
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- stage Q: [plane][ks][query tile] blocks of 1 KiB, copied as they are (lane-linear) ----
   {
     const int nq = (NP == 1 ? 1 : 2) * nks * 2 * 64;   // 16-B pieces
@@ -390,30 +415,7 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[i][qt][r] = 0.f;
-  long long koff[NKTW];
-  bool kval[NKTW];
-#pragma unroll
-  for (int i = 0; i < NKTW; ++i) {
-    const int kt = wave + 8 * i;
-    kval[i] = (kt * 16 < T);                          // wave-uniform (T % 16 == 0)
-    koff[i] = ((long long)(min(kt, (T >> 4) - 1) * ldb + kcs) * 64 + lane) * 8;     // + ks * 512 halfs per channel step
-  }
-  if (kval[0]) {
-    // the K rows of the next DK channel steps are in flight while a step feeds the matrix cores: the kernel is bound by the
-    // round trips of these loads (one workgroup per CU, two waves per SIMD), so the ring is as deep as the registers allow
-    h8 kh[DK][NKTW], kl[DK][NKTW];
-    auto loadK = [&](int ks, int buf) {
-#pragma unroll
-      for (int i = 0; i < NKTW; ++i) {
-        kh[buf][i] = *reinterpret_cast<const h8*>(PH + koff[i] + ks * 512);
-        if (NP == 3) kl[buf][i] = *reinterpret_cast<const h8*>(PL + koff[i] + ks * 512);
-      }
-    };
-#pragma unroll
-    for (int u = 0; u < DK; ++u) loadK(u, u);                      // nks % DK == 0 (launcher)
-    // (scheduling barriers pin the loads where they are written: left alone, the machine scheduler sinks every load next to
-    // its use to save registers, which is exactly the exposed round trip per step the ring exists to avoid)
-    __builtin_amdgcn_sched_barrier(0);
+  {
     for (int ks = 0; ks < nks; ks += DK) {
 #pragma unroll
       for (int u = 0; u < DK; ++u) {
@@ -441,6 +443,29 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   }
 
   ATTN_STAMP(2);
+  // ---- phase 2 set-up, and its first two key steps of V^T go out now: they fly while the softmax runs ----
+  const int nitems = (Dh >> 4) * 2;
+  const int nj = (nitems - wave + 7) >> 3;           // items of this wave (wave-uniform): JC, or 0 for the waves beyond the items
+  const int qt = wave & 1, dtb = wave >> 1;
+  float* __restrict__ outz = p.out + (long long)b * p.o_img_stride + (long long)head * p.o_head_stride;
+  const char* pb = Ps + ((size_t)(qt * nsteps * 4 + g) * 16 + r16) * 16;
+  const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
+  int voff[JC];
+#pragma unroll
+  for (int jj = 0; jj < JC; ++jj)                    // (waves beyond the items read a clamped, valid tile and discard it)
+    voff[jj] = ((vdt0 + min(dtb + 4 * jj, (Dh >> 4) - 1)) * nsteps * 64 + lane) * 8;   // + st * 512 halfs per key step
+  h8 vh[2][JC], vl[2][JC];
+  auto loadV = [&](int st, int buf) {
+#pragma unroll
+    for (int jj = 0; jj < JC; ++jj) {
+      vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 512);
+      if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 512);
+    }
+  };
+  loadV(0, 0);
+  loadV(min(1, nsteps - 1), 1);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- softmax over the keys of query (q0 + qt*16 + r16): accumulator element r of tile i is key (wave + 8i)*16 + 4g + r ----
   float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -514,32 +539,12 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   // ---- phase 2: O^T = V^T P^T; items (16-channel tile dt, query tile qt): wave w owns the items w, w+8, ... -- all of query
   // tile w & 1, channel tiles (w >> 1) + 4j -- and runs up to JC of them side by side: one P fragment per key step feeds JC
   // accumulators, and the V^T rows of the next step are in flight meanwhile ----
-  const int nitems = (Dh >> 4) * 2;
-  const int nj = (nitems - wave + 7) >> 3;           // items of this wave (wave-uniform): JC, or 0 for the waves beyond the items
-  const int qt = wave & 1, dtb = wave >> 1;
-  float* __restrict__ outz = p.out + (long long)b * p.o_img_stride + (long long)head * p.o_head_stride;
-  const char* pb = Ps + ((size_t)(qt * nsteps * 4 + g) * 16 + r16) * 16;
-  const size_t plo = (size_t)2 * nsteps * 4 * 16 * 16;
   if (nj > 0) {
     f32x4 o[JC];
-    int voff[JC];
 #pragma unroll
-    for (int jj = 0; jj < JC; ++jj) {
+    for (int jj = 0; jj < JC; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[jj][r] = 0.f;
-      voff[jj] = ((vdt0 + dtb + 4 * jj) * nsteps * 64 + lane) * 8;   // + st * 512 halfs per key step (an image's V^T is far below 2^31 halfs)
-    }
-    h8 vh[2][JC], vl[2][JC];
-    auto loadV = [&](int st, int buf) {
-#pragma unroll
-      for (int jj = 0; jj < JC; ++jj) {
-        vh[buf][jj] = *reinterpret_cast<const h8*>(VH + voff[jj] + st * 512);
-        if (NP == 3) vl[buf][jj] = *reinterpret_cast<const h8*>(VL + voff[jj] + st * 512);
-      }
-    };
-    loadV(0, 0);
-    loadV(min(1, nsteps - 1), 1);
-    __builtin_amdgcn_sched_barrier(0);
     for (int st = 0; st < nsteps; st += 2) {          // nsteps is even or 1 (T % 64 == 0 or T == 32: launcher)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
