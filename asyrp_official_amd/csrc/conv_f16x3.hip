@@ -855,12 +855,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   * the weight slices through registers (global_load_dwordx4 -> ds_write_b128, two sets, two steps ahead): 30-45 % SLOWER
 //     (profiles/rd3e_*_NEGATIVE.txt).
 // Neither the latency nor the rate of the LDS-DMA fill is what these steps wait for; the two-slot LDS-DMA loop stays.
-template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3>
+//   <8, 2, 16, 1, 3, true>: the QUAD form for the 8 x 8-pixel layers.  The 64-pixel form gives one workgroup 12 matrix
+//              instructions per wave and K-step and re-streams a 2.4 MB weight slab per image: 0.69 us per step for 0.08 us of
+//              matrix work, 81 TFLOP/s, 128 workgroups on 256 CUs at B = 32 (and neither a deeper weight ring nor weights
+//              through registers helped, see above).  Here one workgroup takes FOUR images as a 2 x 2 arrangement of 8 x 8 patches
+//              -- the main tile's shape: 256 pixels x 128 channels, 48 matrix instructions per wave and step, one weight slice
+//              feeds four images -- each image with its own zero border in the 20 x 20 halo tile, and the K range is split over
+//              gridDim.y (GemmArgs.sk): every workgroup writes alpha * acc of its range to `part`, launch_splitk_reduce adds the
+//              ranges in a fixed order with bias / residual / statistics.  Per image the products and their order are those
+//              of any other K32 form over the same K range, and an image's partial sums do not depend on which images share its
+//              workgroup: batch invariance stays bitwise.
+template <int NW_, int WN_, int PW_ = 16, int STRIDE_ = 1, int KS_ = 3, bool QUAD_ = false>
 struct K32Cfg {
   static constexpr int NW = NW_, WN = WN_, WM = NW / WN, NT = NW * 64, TN = 8 / WN, STRIDE = STRIDE_;
   static constexpr int KS = KS_, NTAPS = KS * KS;              // 3 x 3 taps, or the 2 x 2 taps of one output phase
+  static constexpr bool QUAD = QUAD_;
   static constexpr int PW = PW_, FR = 16 / PW;                 // FR patch rows per 16-row fragment
-  static constexpr int BM = WM * 64, BN = 128, PH = BM / PW, TW = (PW - 1) * STRIDE + KS, TH = (PH - 1) * STRIDE + KS;
+  static constexpr int BM = WM * 64, BN = 128, PH = BM / PW;
+  static constexpr int TW = QUAD ? 20 : (PW - 1) * STRIDE + KS, TH = QUAD ? 20 : (PH - 1) * STRIDE + KS;   // QUAD: 2 x (8 + 2) per axis
   static constexpr int NPIX = TH * TW;                         // halo pixels (324 for the main tile)
   static constexpr int PLANE = (NPIX + 15) / 16 * 16;          // unit-plane pitch in pixels (multiple of 16: 256-B congruent)
   static constexpr int A_BYTES = 4 * PLANE * 16;               // [4 units][PLANE][16 B]
@@ -875,6 +887,7 @@ struct K32Cfg {
   static_assert(NA <= 2 && NSC <= 2 && NSC <= NA, "staging registers");
   static_assert(PW == 16 || PW == 8, "a fragment is one or two patch rows");
   static_assert(KS == 3 || (KS == 2 && STRIDE == 1), "polyphase form: 2 x 2 taps at stride 1");
+  static_assert(!QUAD || (PW == 16 && STRIDE == 1 && KS == 3 && WM == 4), "quad form: 16 x 16 virtual patch of four 8 x 8 images");
 };
 
 // SC: fused 1x1 shortcut.  After the 3x3 slices the flat K sequence continues with Cin2/16 single-tap slices over the raw
@@ -904,11 +917,15 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const int wm = wave / WN, wn = wave - wm * WN;
   // polyphase form: blockIdx.z = image * 4 + output phase (py, px); Hout x Wout are the SOURCE dimensions (the M space)
   constexpr bool POLY = (T::KS == 2);
+  constexpr bool QUAD = T::QUAD;
   constexpr int NTAPS = T::NTAPS, KW = T::KS;
   static_assert(!(POLY && SC), "the polyphase form has no fused shortcut");
-  const int zo = POLY ? (int)blockIdx.z >> 2 : (int)blockIdx.z;
+  static_assert(!(QUAD && (SC || ABL)), "the quad form has no fused shortcut");
+  // quad form: blockIdx.z = group of four images (zo = its first image), blockIdx.y = N block * sk + K range
+  const int zo = POLY ? (int)blockIdx.z >> 2 : (QUAD ? (int)blockIdx.z * 4 : (int)blockIdx.z);
   const int phy = POLY ? ((int)blockIdx.z >> 1) & 1 : 0, phx = POLY ? (int)blockIdx.z & 1 : 0;
-  const int n0 = blockIdx.y * BN;
+  const int sk = QUAD ? p.sk : 1, ks_id = QUAD ? (int)blockIdx.y % sk : 0;
+  const int n0 = (QUAD ? (int)blockIdx.y / sk : (int)blockIdx.y) * BN;
   int bx = blockIdx.x;
   if (p.xmap) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);   // XCD-aware block -> tile map (see igemm_f16x3_kernel)
   const int tiles_x = (p.Wout + PW - 1) / PW;
@@ -926,12 +943,24 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   // ---- A staging map: work item = (halo pixel, 8-channel half), as in igemm_f16x3_kernel ----
   const int hf = tid & 1;
   int aoff[NA];   // source pixel index, -1 = zero padding, -2 = no work item
+  int aimg[NA];   // quad form: the item's image within the group (its scale/shift row)
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int u = tid + i * NT;
     const int pix = u >> 1;
     int off = -2;
-    if (u < NU) {
+    aimg[i] = 0;
+    if (QUAD) {
+      if (u < NU) {
+        // halo pixel (iy, ix) of the 20 x 20 tile = image (iy / 10, ix / 10) of the group, its pixel (iy % 10 - 1, ix % 10 - 1);
+        // per-image tensors are dense (a_zo == 64 * lda: launcher), so image q's pixel l sits at row q * 64 + l of the group
+        const int iy = pix / TW, ix = pix - iy * TW;
+        const int qy = iy / 10, ly = iy - qy * 10 - 1, qx = ix / 10, lx = ix - qx * 10 - 1;
+        const int q = qy * 2 + qx;
+        aimg[i] = q;
+        off = (ly >= 0 && ly < 8 && lx >= 0 && lx < 8 && zo + q < p.Z) ? q * 64 + ly * 8 + lx : -1;
+      }
+    } else if (u < NU) {
       const int iy = pix / TW, ix = pix - iy * TW;
       // polyphase: phase 0 reads source rows (i-1, i), phase 1 rows (i, i+1): the halo origin moves with the phase
       const int gy = oy0 * STRIDE - (POLY ? 1 - phy : p.pad) + iy, gx = ox0 * STRIDE - (POLY ? 1 - phx : p.pad) + ix;
@@ -962,17 +991,24 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   auto write_A = [&](int chunk, int buf) {
     const int c = chunk * XKC + hf * 8;
     float4 sreg[4];
-    if (ps) {
+    if (ps && !QUAD) {
       sreg[0] = *reinterpret_cast<const float4*>(ps + c);
       sreg[1] = *reinterpret_cast<const float4*>(ps + c + 4);
       sreg[2] = *reinterpret_cast<const float4*>(psh + c);
       sreg[3] = *reinterpret_cast<const float4*>(psh + c + 4);
     }
-    const float sc[8] = {sreg[0].x, sreg[0].y, sreg[0].z, sreg[0].w, sreg[1].x, sreg[1].y, sreg[1].z, sreg[1].w};
-    const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (aoff[i] == -2) continue;
+      if (ps && QUAD) {   // every halo pixel belongs to one of the group's four images: its own scale / shift row
+        const long long ro = (long long)aimg[i] * ldps + c;
+        sreg[0] = *reinterpret_cast<const float4*>(ps + ro);
+        sreg[1] = *reinterpret_cast<const float4*>(ps + ro + 4);
+        sreg[2] = *reinterpret_cast<const float4*>(psh + ro);
+        sreg[3] = *reinterpret_cast<const float4*>(psh + ro + 4);
+      }
+      const float sc[8] = {sreg[0].x, sreg[0].y, sreg[0].z, sreg[0].w, sreg[1].x, sreg[1].y, sreg[1].z, sreg[1].w};
+      const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
       if (aoff[i] >= 0) {
@@ -1015,7 +1051,10 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   // ---- operand addressing: lane = (row r16, k group kq = 2 * tap-of-the-step + channel half) ----
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   // row r16 of row block tm = patch pixel ((wm * 4 + tm) * FR + r16 / PW, r16 % PW)
-  const int a_lane = (kh * PLANE + ((wm * 4 * FR + r16 / PW) * STRIDE) * TW + (r16 % PW) * STRIDE) * 16;
+  // (quad form: patch row py = 4 wm + tm lies in image row block py >> 3, column r16 in block r16 >> 3; each block has its own
+  //  one-pixel border, i.e. two extra halo rows / columns in front of the second block)
+  const int a_lane = QUAD ? (kh * PLANE + (wm * 4 + 2 * (wm >> 1)) * TW + r16 + 2 * (r16 >> 3)) * 16
+                          : (kh * PLANE + ((wm * 4 * FR + r16 / PW) * STRIDE) * TW + (r16 % PW) * STRIDE) * 16;
   constexpr int A_TM = FR * STRIDE * TW * 16;  // byte pitch between row blocks (+ 2 * PLANE * 16 for x_lo, + the tap offset)
   const int b_lane = tp * B_BYTES + (kh * BN + wn * WCH + r16) * 16;      // + tn * 256 (+ 2 * BN * 16 for w_lo) + slot
 
@@ -1027,9 +1066,12 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
-  issue_slot(0, 0);
-  gload_A(0);
-  write_A(0, 0);
+  // split-K (quad form): this workgroup's chunks [cb, ce), an even number of them (launcher), i.e. whole K = 32 steps
+  const int cb = QUAD ? ks_id * (nch / sk) : 0, ce = QUAD ? cb + nch / sk : nch;
+  const int s_first = cb * NTAPS / 2;
+  issue_slot(s_first, s_first & 1);
+  gload_A(cb);
+  write_A(cb, cb & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1123,11 +1165,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   };
 
-  const int nsteps3 = nch * NTAPS / 2;
+  const int nsteps3 = ce * NTAPS / 2;            // one past this workgroup's last 3x3 step (absolute step index)
   const int nsc = SC ? p.Cin2 / (2 * XKC) : 0;
   const int nsteps = nsteps3 + nsc;
-  int c0 = 0, t0 = 0, staged = 0;   // (c0, t0): chunk and tap of the step's first slice
-  for (int s = 0; s < nsteps3; ++s) {
+  int c0 = cb, t0 = 0, staged = cb;   // (c0, t0): chunk and tap of the step's first slice
+  for (int s = s_first; s < nsteps3; ++s) {
     if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
@@ -1143,7 +1185,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     // the halo tile of the chunk the NEXT step's second slice belongs to must be in LDS before the barrier below; its
     // buffer held chunk need-2, last read at least one barrier ago
     const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
-    if (need > staged && need < nch && !(abl & 8)) {
+    if (need > staged && need < ce && !(abl & 8)) {
       gload_A(need);
       write_A(need, need & 1);
       staged = need;
@@ -1174,6 +1216,26 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   }
 
+  if (QUAD) {
+    // raw partial sums of this K range: part[range][image][pixel][Cout]; bias / residual / statistics belong to launch_splitk_reduce
+    const int gq = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + wn * WCH + tn * 16 + r16;
+      if (n >= Cout) continue;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const int py = wm * 4 + tm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 4 * gq + r;
+          const int img = zo + (py >> 3) * 2 + (px >> 3);
+          if (img < p.Z) p.part[(((size_t)ks_id * p.Z + img) * 64 + (py & 7) * 8 + (px & 7)) * Cout + n] = acc[tm][tn][r] * p.alpha;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r ----
   float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
   const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
@@ -1291,11 +1353,13 @@ using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
 using K32Up = K32Cfg<8, 2, 16, 1, 2>;
+using K32Quad = K32Cfg<8, 2, 16, 1, 3, true>;
 template <class T, bool SC, bool ABL = false, int NP = 3>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
-  const int gx = ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
-  const int gy = (a.Cout + T::BN - 1) / T::BN;
-  dim3 grid(gx, gy, a.Z * (T::KS == 2 ? 4 : 1)), block(T::NT);   // polyphase form: one z-slice per (image, output phase)
+  const int gx = T::QUAD ? 1 : ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
+  const int gy = ((a.Cout + T::BN - 1) / T::BN) * (T::QUAD ? a.sk : 1);
+  // polyphase form: one z-slice per (image, output phase); quad form: one per group of four images, K ranges along y
+  dim3 grid(gx, gy, T::QUAD ? (a.Z + 3) / 4 : a.Z * (T::KS == 2 ? 4 : 1)), block(T::NT);
   GemmArgs ax = a;
   ax.xmap = (xcd_map_enabled() && gx >= 16 && (gx & 7) == 0 && (gy * (long long)gx) % 8 == 0) ? 1 : 0;
   static bool attr_set[16] = {};
@@ -1382,8 +1446,16 @@ static bool k32up_ok(const GemmArgs& a) {
   return a.poly && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && !a.resid && (a.Cin & 31) == 0 && a.Cin >= 32 &&
          a.Hin == a.Hout && a.Win == a.Wout && a.w_phase > 0 && is_vec(a);
 }
+// quad form (split-K over four-image groups) for the 8 x 8 layers: dense per-image tensors, an even number of chunks per K range
+static bool k32quad_ok(const GemmArgs& a) {
+  if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && !a.poly && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8)) return false;
+  if (a.sk < 2 || !a.part || (a.Cin & 31) || ((a.Cin / XKC) % (2 * a.sk)) != 0 || !is_vec(a)) return false;
+  if (a.a0_zo != 64LL * a.lda0 || (a.a1 && a.a1_zo != 64LL * a.lda1)) return false;
+  return true;
+}
 static int eff_tile_x(const GemmArgs& a) {
   if (a.poly) return XT_256x128K32UP;
+  if (a.tile == XT_256x128K32Q) return k32quad_ok(a) ? XT_256x128K32Q : XT_64x64;
   if (a.stride == 2) return (k32s2_ok(a) && k32_preferred() && a.tile != XT_64x128) ? XT_64x128K32S2 : XT_64x128;
   int t = requested_tile_x(a);
   if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
@@ -1455,6 +1527,7 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
     return big ? launch_x<X256x128_1plain, false, false, false, false, NP>(a, s) : launch_x<X64x128_1plain, false, false, false, false, NP>(a, s);
   }
   if (a.poly) return k32up_ok(a) ? launch_k32<K32Up, false, false, NP>(a, s) : hipErrorInvalidValue;
+  if (tile == XT_256x128K32Q) return launch_k32<K32Quad, false, false, NP>(a, s);
   if (a.abl && NP != 3) return hipErrorInvalidValue;
   if (a.abl) {   // timing ablations of the main tile: instantiated in the profiling library only (libasyrp_hip_bench.so)
 #ifdef ASYRP_BENCH_HOOKS
@@ -1517,8 +1590,16 @@ int splitk_factor(const GemmArgs& a) {
   if (a.math != MATH_F16X3 || !a.wpk || a.ks != 3 || a.stride != 1 || a.ups || a.s0 || a.rups || a.abl) return 1;
   // measured (profiles/r01_conv_microbench_kb8_splitk.txt, B=32): 1024->512 @8x8 179 -> 134 us; 512->512 @8x8 no gain (91 us
   // either way: with 32 chunks a workgroup's fixed prologue/epilogue latency equals its share of the loop)
-  if (a.Hout * a.Wout > 64 || a.Cin < 1024 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
-  return 8;
+  // round 3: with the quad form (four images per workgroup, K32Cfg<8, 2, 16, 1, 3, true>) every 8 x 8 layer with Cin % 256 == 0
+  // splits, 512 -> 512 included; the 64 x 64 tile keeps the old rule (Cin >= 1024)
+  if (a.Hout * a.Wout > 64 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
+  if (splitk_quad(a)) return 8;
+  return a.Cin >= 1024 ? 8 : 1;
+}
+bool splitk_quad(const GemmArgs& a) {
+  static const bool on = [] { const char* e = getenv("ASYRP_QUAD8"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
+  return on && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
+         (a.Cin % 256) == 0 && a.a0_zo == 64LL * a.lda0 && (!a.a1 || a.a1_zo == 64LL * a.lda1);
 }
 
 __global__ void splitk_reduce_kernel(const GemmArgs p, int HW) {

@@ -74,6 +74,7 @@ enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4,
        XT_64x128K32 = 9 /* 8 x 8 patch (one 8 x 8 image), 8 waves of 64 pixels x 16 channels */,
        XT_64x128K32S2 = 10 /* stride 2 (DDPM Downsample): 4 x 16 output patch, 8 waves of 64 pixels x 16 channels */,
        XT_256x128K32UP = 11 /* polyphase form of the main tile: nearest x2 + 3x3 as four 2x2-tap phases on the source grid */,
+       XT_256x128K32Q = 14 /* quad form for the 8 x 8 layers: four images per workgroup, split-K (GemmArgs.sk / part) */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
@@ -114,6 +115,7 @@ int gn_nblk_of(int HW);                       // M-blocks launch_gn_partial writ
 hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int splitk_stat_blocks(int HW);
 int splitk_factor(const GemmArgs& a);   // 1 = none; a function of the LAYER SHAPE only (batch-invariant results)
+bool splitk_quad(const GemmArgs& a);    // the split launch runs on the quad form (XT_256x128K32Q) instead of the 64x64 tile
 int gemm_main_tile();
 bool gemm_can_fuse_shortcut(const GemmArgs& a);   // true when launch_gemm_f16x3 would run `a` (with s0/Cin2 set) on the fusing tile
 int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats

@@ -285,9 +285,9 @@ class Engine:
         if fam == 1:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
                     12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
-            if tid in (7, 8, 9, 10, 11):    # the v_mfma_f32_16x16x32_f16 kernels: 256- / 128- / 64-pixel forms, stride 2, polyphase x2
+            if tid in (7, 8, 9, 10, 11, 14):    # the v_mfma_f32_16x16x32_f16 kernels: 256- / 128- / 64-pixel forms, stride 2, polyphase x2, quad 8x8
                 return "f16x3", "asyrp::igemm_f16x3_k32_kernel<asyrp::K32Cfg<%s>>" % {7: "8, 2", 8: "8, 4", 9: "8, 8, 8", 10: "8, 8, 16, 2",
-                                                                                     11: "8, 2, 16, 1, 2"}[tid]
+                                                                                     11: "8, 2, 16, 1, 2", 14: "8, 2, 16, 1, 3, true"}[tid]
             return "f16x3", "asyrp::igemm_f16x3_kernel<asyrp::XCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))
         tile = {1: (2, 2, 2, 2), 2: (2, 2, 2, 1), 3: (2, 2, 1, 1), 4: (4, 1, 1, 1)}.get(tid, (0,) * 4)
         return "f32", "asyrp::igemm_f32_kernel<asyrp::TileCfg<%d, %d, %d, %d, %d, %d>>" % (tile + (ks, stride))

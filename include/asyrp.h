@@ -231,7 +231,8 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  *                             channel counts are multiples of 32), 8=its 128-pixel form (16x16-pixel layers), 9=its 8x8-patch form, 10=its stride-2 form,
  *                             11=the polyphase form of tile 7 for "nearest x2 then 3x3" (Upsample.conv / ResBlock(up=True)): four
  *                             phase-collapsed 2x2-tap convolutions on the source grid, 4/9 of the products; its FLOPs are
- *                             counted as issued (4 taps), 12=256x32),
+ *                             counted as issued (4 taps), 12=256x32, 14=the quad form of tile 7 for the 8x8-pixel layers: four images per
+ *                             workgroup, split-K with a fixed-order reduce),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */

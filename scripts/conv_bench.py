@@ -106,6 +106,13 @@ if __name__ == "__main__":
                 r = sorted(run(H, Ch, 0, Ch, 3, stride=2, pro=0, math=math, iters=8) for _ in range(5))[2]
                 print(f"  {math:5s} stride 2 {Ch}->{Ch} @{H}->{H // 2}: {r[0] * 1e3:7.1f} us {r[1]:6.1f} TFLOP/s", flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "quad":      # 8x8 layers: run once with ASYRP_QUAD8=0 and once with the default
+        print(f"-- B={B}, ASYRP_QUAD8={os.environ.get('ASYRP_QUAD8', 'default')}: 8x8 layers on the launcher's choice (incl. the reduce launch); us per layer")
+        for math in ("f16x3", "f16"):
+            for (Ch, C1, Co, kw) in ((512, 0, 512, {}), (512, 0, 512, dict(res=1)), (512, 512, 512, {}), (1024, 0, 1024, {})):
+                r = sorted(run(8, Ch, C1, Co, 3, math=math, iters=10, **kw) for _ in range(5))[2]
+                print(f"  {math:5s} {Ch}+{C1}->{Co} @8 {kw}: {r[0] * 1e3:7.1f} us {r[1]:6.1f} TFLOP/s", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")

@@ -13,13 +13,13 @@ import sys
 
 def family(name):
     """rocprofv3 kernel name -> the short family name of bench.py's kernel_families (asyrp_official_amd/engine.py variant_name)."""
-    m = re.search(r"igemm_f16x3_k32_kernel<asyrp::K32Cfg<([\d, ]+)>", name)
+    m = re.search(r"igemm_f16x3_k32_kernel<asyrp::K32Cfg<([\w, ]+)>", name)
     if m:
-        p = [int(v) for v in m.group(1).split(",")]
-        dflt = [None, None, 16, 1, 3]
+        p = [v.strip() for v in m.group(1).split(",")]
+        dflt = [None, None, "16", "1", "3", "false"]
         while len(p) > 2 and p[-1] == dflt[len(p) - 1]:
             p.pop()
-        return "asyrp::igemm_f16x3_k32_kernel<asyrp::K32Cfg<%s>>" % ", ".join(map(str, p))
+        return "asyrp::igemm_f16x3_k32_kernel<asyrp::K32Cfg<%s>>" % ", ".join(p)
     m = re.search(r"igemm_f16x3_kernel<asyrp::XCfg<([\d, ]+)>", name)
     if m:
         p = [v.strip() for v in m.group(1).split(",")][:6]

@@ -450,3 +450,33 @@ def test_attention_split_plane_kernel_refuses_other_shapes():
         out = torch.empty((B, C, T), device="cuda")
         with pytest.raises(_lib.AsyrpError, match="not covered"):
             _lib.check(lib.asyrp_op_attention(0, _p(qd), B, C, T, heads, 3, _p(out), None))
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("B,C0,C1,Cout,pro,res", [(5, 512, 0, 512, True, True), (4, 512, 512, 512, True, False), (1, 512, 0, 160, False, False),
+                                                   (9, 256, 256, 256, True, True)])
+def test_quad_form_8x8_layers(B, C0, C1, Cout, pro, res, math):
+    """The launcher's choice for 8 x 8 layers with Cin % 256 == 0: four images per workgroup (2 x 2 arrangement of 8 x 8 patches, each
+    with its own zero border), K split 8 ways, fixed-order reduce with bias / residual -- ragged groups (B = 5, 9, 1), concat input,
+    per-image GroupNorm prologue, partial N tile."""
+    x0 = hash_normal(f"q8.x0.{B}.{C0}", (B, C0, 8, 8))
+    x1 = hash_normal(f"q8.x1.{B}.{C1}", (B, C1, 8, 8)) if C1 else None
+    Cin = C0 + C1
+    w = hash_uniform(f"q8.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"q8.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform(f"q8.g.{Cin}", (Cin,)), 0.1 * hash_uniform(f"q8.be.{Cin}", (Cin,))) if pro else None
+    r = hash_normal(f"q8.r.{B}.{Cout}", (B, Cout, 8, 8)) if res else None
+    ca = hash_normal(f"q8.ca.{B}.{Cout}", (B, Cout))
+    kw = dict(x1=x1, gn=gn, silu=pro, residual=r, chan_add=ca)
+    got = hip_conv(x0, w, b, math=math, **kw)
+    want = ref_conv(x0, w, b, **kw)
+    if math == "f16x3":
+        assert_close(got, want, what="quad 8x8 form", **TIGHT)
+        # image i alone == image i inside the batch, bit for bit (its partial sums do not depend on its group)
+        i = B - 1
+        alone = hip_conv(x0[i:i + 1], w, b, x1=None if x1 is None else x1[i:i + 1], gn=gn, silu=pro,
+                         residual=None if r is None else r[i:i + 1], chan_add=ca[i:i + 1], math=math)
+        assert torch.equal(alone[0], got[i]), "quad form: result depends on the batch"
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
