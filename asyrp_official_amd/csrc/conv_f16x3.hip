@@ -1000,7 +1000,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (aoff[i] == -2) continue;
-      if (ps && QUAD) {   // every halo pixel belongs to one of the group's four images: its own scale / shift row
+      if (ps && QUAD && aoff[i] >= 0) {   // every halo pixel belongs to one of the group's four images: its own scale / shift row
+                                          // (border pixels and the images a ragged last group lacks are zeros: no row to read)
         const long long ro = (long long)aimg[i] * ldps + c;
         sreg[0] = *reinterpret_cast<const float4*>(ps + ro);
         sreg[1] = *reinterpret_cast<const float4*>(ps + ro + 4);

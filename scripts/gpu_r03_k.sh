@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-(timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -12) > $OUT/pytest.log
+(timeout 600 python -m pytest tests -m gpu -q -v 2>&1 | grep -E "FAILED|ERROR|passed|failed|Fatal|test_.*(PASSED|FAILED)" | tail -400) > $OUT/pytest.log
 tail -5 $OUT/pytest.log
 (ASYRP_QUAD8=0 timeout 200 python scripts/conv_bench.py 32 quad 2>&1 | grep -v amdgpu.ids | tail -10) > $OUT/ab_quad_off.txt
 (timeout 200 python scripts/conv_bench.py 32 quad 2>&1 | grep -v amdgpu.ids | tail -10) > $OUT/ab_quad_on.txt
