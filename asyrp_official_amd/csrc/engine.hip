@@ -680,7 +680,9 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     if (sc0) {   // try the fused 1x1 shortcut: needs the fused weight image and the main tile
       auto fit = c.e->xw.find(wname + "#sc");
       const float* fb = P(c, bname + "#sc");
-      if (fit != c.e->xw.end() && fb && !resid) {
+      // 8 x 8 layers: the quad form (four images per workgroup, split-K) without the fusion beats the fused 64-pixel form --
+      // 46 us + a 1x1 launch against 150 us -- so these blocks take the two-launch form (the shortcut enters the reduce as the residual)
+      if (fit != c.e->xw.end() && fb && !resid && !splitk_quad(g)) {
         GemmArgs t = g;
         t.s0 = sc0->p; t.sc0 = sc0->C; t.lds0 = sc0->C; t.s0_zo = sc0->per_image();
         if (sc1) { t.s1 = sc1->p; t.sc1 = sc1->C; t.lds1 = sc1->C; t.s1_zo = sc1->per_image(); }
