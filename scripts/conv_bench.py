@@ -113,6 +113,19 @@ if __name__ == "__main__":
                 r = sorted(run(8, Ch, C1, Co, 3, math=math, iters=10, **kw) for _ in range(5))[2]
                 print(f"  {math:5s} {Ch}+{C1}->{Co} @8 {kw}: {r[0] * 1e3:7.1f} us {r[1]:6.1f} TFLOP/s", flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "onebyone":  # 1x1 GEMMs of the attention blocks: tile sweep (2 = 128x128, 3 = 64x128, 4 = 64x64, 1 = 256x128)
+        print(f"-- B={B}: 1x1 GEMMs at 16x16 / 8x8, us per launch by tile (0 = launcher's choice)")
+        for (H, Ci, Co, pro) in ((16, 512, 1536, 1), (16, 512, 512, 0), (8, 512, 1536, 1), (8, 512, 512, 0), (8, 1024, 512, 0), (32, 512, 1536, 1), (32, 512, 512, 0)):
+            tiles = (0, 1, 2, 3, 4)
+            r = {t: [] for t in tiles}
+            for rnd in range(5):
+                for t in tiles:
+                    try:
+                        r[t].append(run(H, Ci, 0, Co, 1, pro=pro, res=(0 if pro else 1), tile=t, iters=10)[0] * 1e3)
+                    except Exception:
+                        r[t].append(float("nan"))
+            print(f"  {Ci}->{Co} @{H}: " + "  ".join(f"t{t} {sorted(r[t])[2]:6.1f}" for t in tiles), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ab67":      # interleaved A/B: 8-wave tile on 32x32x16 (6) vs on 16x16x32 (7)
         tiles = (6, 7)
         print(f"-- A/B interleaved, B={B}: 8-wave 256x128 tile on v_mfma_f32_32x32x16_f16 (6) vs v_mfma_f32_16x16x32_f16 (7)")
