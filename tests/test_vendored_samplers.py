@@ -138,3 +138,30 @@ def test_samplers_drive_the_engine_unets():
             # pred_xstart multiplies an eps difference by sqrt(1/alpha_bar - 1) (up to 13 at t=701): scale the tolerance like the
             # x0_t checks of test_gpu_edit.py
             _check(diff, model, x, t, g, f"{name}.t{tv}", "cuda", dict(rtol=1e-3, atol=2e-3 if tv else 1e-4))
+
+
+@pytest.mark.gpu
+def test_sampler_kernel_chunks_large_batches_and_eta():
+    """asyrp_sampler_update takes its coefficient rows 32 images per launch: a batch of 40 (two chunks, mixed timesteps, eta > 0 with
+    supplied noise) equals the rows applied image by image in float64."""
+    from asyrp_official_amd.gaussian_diffusion import GaussianDiffusion, SamplerSchedule, sampler_update
+    B = 40
+    x = hash_normal("samp.x", (B, 3, 16, 16), seed=3)
+    mo = hash_normal("samp.mo", (B, 6, 16, 16), seed=4)
+    nz = hash_normal("samp.nz", (B, 3, 16, 16), seed=5)
+    t = np.array([(37 * i) % 1000 for i in range(B)])
+    t[3] = 0
+    sch = SamplerSchedule(BETAS)
+    for kind, kw in (("ddim", dict(eta=0.7)), ("posterior", {})):
+        rows = sch.rows(kind, t, var_type="learned_range", clip=True, **kw)
+        got_s, got_x0, got_lv = sampler_update(x.cuda(), mo.cuda(), rows, noise=nz.cuda(), want_log_variance=True)
+        want_s, want_x0, want_lv = _apply_rows(rows, x, mo, nz)
+        assert_close(got_s, want_s, what=f"{kind} sample, B=40", **TIGHT)
+        assert_close(got_x0, want_x0, what=f"{kind} pred_xstart, B=40", **TIGHT)
+        assert_close(got_lv, want_lv, what=f"{kind} log_variance, B=40", **TIGHT)
+    # the class picks the noise path by itself when eta > 0
+    diff = GaussianDiffusion(betas=BETAS, model_var_type="fixed_small")
+    tt = torch.from_numpy(t).cuda()
+    out = diff.ddim_sample(lambda x_, t_, **k: mo[:, :3].cuda(), x.cuda(), tt, eta=0.5, noise=nz.cuda())
+    rows = sch.rows("ddim", t, var_type="fixed_small", clip=True, eta=0.5)
+    assert_close(out["sample"], _apply_rows(rows, x, mo[:, :3], nz)[0], what="ddim_sample eta=0.5", **TIGHT)
