@@ -1310,7 +1310,7 @@ static bool is_vec(const GemmArgs& a) {
 }
 
 // A/B switch of the XCD-aware tile map (ASYRP_XCD_MAP=0 disables it)
-static bool xcd_map_enabled() {
+bool xcd_map_enabled() {
   static const bool on = [] { const char* e = getenv("ASYRP_XCD_MAP"); return !(e && e[0] == '0'); }();
   return on;
 }
@@ -1455,6 +1455,7 @@ static bool k32quad_ok(const GemmArgs& a) {
   return true;
 }
 static int eff_tile_x(const GemmArgs& a) {
+  if (a.tile == XT_G1_256 || a.tile == XT_G1_128) return a.tile;   // set by the engine only after gemm1x1_ok()
   if (a.poly) return XT_256x128K32UP;
   if (a.tile == XT_256x128K32Q) return k32quad_ok(a) ? XT_256x128K32Q : XT_64x64;
   if (a.stride == 2) return (k32s2_ok(a) && k32_preferred() && a.tile != XT_64x128) ? XT_64x128K32S2 : XT_64x128;
@@ -1483,9 +1484,9 @@ int gemm_mblocks(const GemmArgs& a) {
   if (a.poly) return 4 * ((a.Hout + K32Up::PH - 1) / K32Up::PH) * ((a.Wout + K32Up::PW - 1) / K32Up::PW);   // 4 phases per image
   if (eff_tile_x(a) == XT_64x128K32S2) return ((a.Hout + K32S2::PH - 1) / K32S2::PH) * ((a.Wout + K32S2::PW - 1) / K32S2::PW);
   switch (eff_tile_x(a)) {
-    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32:
+    case XT_256x128: case XT_256x64: case XT_256x128W8: case XT_256x128K32: case XT_256x32: case XT_G1_256:
       bm = 256; break;
-    case XT_128x128: case XT_128x128K32: bm = 128; break;
+    case XT_128x128: case XT_128x128K32: case XT_G1_128: bm = 128; break;
     default: bm = 64;
   }
   if (a.ks == 1) return (a.Hout * a.Wout + bm - 1) / bm;
@@ -1572,6 +1573,8 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gemm_f16x3(const GemmArgs& a, hipStream_t s) {
+  if (a.np != 0 && a.np != 1 && a.np != 3) return hipErrorInvalidValue;
+  if (a.tile == XT_G1_256 || a.tile == XT_G1_128) return launch_gemm1x1(a, s);   // gemm1x1.hip (its own weight image in a.wpk)
   // a.np: matrix products per term -- 3 (two-term split, fp32-equivalent; 0 means 3) or 1 (single f16 product, conv_math "f16")
   if (a.np == 1) return launch_gemm_f16x3_np<1>(a, s);
   if (a.np != 0 && a.np != 3) return hipErrorInvalidValue;

@@ -452,6 +452,37 @@ int pack_x3(asyrp_engine* e, const std::string& name, const std::vector<float>& 
   return 0;
 }
 
+// 1x1 conv weight [Cout][Cin] -> the fragment-major image of gemm1x1.hip under `name` + "#g1" (same power-of-two scale rule)
+int pack_g1(asyrp_engine* e, const std::string& name, const std::vector<float>& w, int cout, int cin) {
+  float mx = 0.f;
+  for (float v : w) mx = std::max(mx, std::fabs(v));
+  float wscale = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) wscale = std::ldexp(1.0f, 10 - (int)std::floor(std::log2(mx)));
+  const std::string key = name + "#g1";
+  asyrp_engine::XW x;
+  auto it = e->xw.find(key);
+  const size_t halfs = gemm1x1_packed_halfs(cout, cin);
+  if (it != e->xw.end() && it->second.halfs == halfs) {
+    x = it->second;
+  } else {
+    if (it != e->xw.end()) { (void)hipFree(it->second.p); e->param_bytes -= it->second.halfs * 2; }
+    HIPCHK(hipMalloc(&x.p, halfs * 2));
+    x.halfs = halfs;
+    e->param_bytes += halfs * 2;
+  }
+  x.wscale = wscale;
+  x.cout_pad = ((cout + 127) / 128) * 128;
+  float* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, std::max<size_t>(w.size(), 1) * sizeof(float)));
+  HIPCHK(hipMemcpy(tmp, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t le = launch_gemm1x1_pack(tmp, x.p, cout, cin, wscale, nullptr);
+  hipError_t se = hipDeviceSynchronize();
+  (void)hipFree(tmp);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "1x1 weight packing failed for " + name);
+  e->xw[key] = x;
+  return 0;
+}
+
 // 3x3 conv weight + the block's 1x1 shortcut weight -> ONE f16x3 image: the shortcut's slices follow the conv's K-steps
 // (conv_f16x3.hip, fused shortcut); one common power-of-two scale.  Stored under `name` + "#sc".
 int pack_x3_fused(asyrp_engine* e, const std::string& name, const std::vector<float>& w3, int cout, int cin3,
@@ -633,6 +664,26 @@ static bool polyphase_enabled() {
   static const bool on = [] { const char* e = getenv("ASYRP_POLYPHASE"); return !(e && e[0] == '0'); }();
   return on;
 }
+// 1x1 convolutions of the 16 x 16 feature maps (the attention blocks of every 256-pixel config) on the barrier-free kernel of gemm1x1.hip;
+// at 32 x 32 and above the 256 x 128 implicit-GEMM tile is faster, at 8 x 8 the 64-pixel tiles (profiles/rd3p_*) (ASYRP_GEMM1X1=0: the implicit-GEMM
+// tiles, for A/B; =256: its 8-wave form); a function of the layer shape only.  Recorded in bench.py's line like the other switches.
+static int gemm1x1_tile() {
+  static const int t = [] {
+    const char* e = getenv("ASYRP_GEMM1X1");
+    if (e && e[0] == '0') return 0;
+    return (e && e[0] == '2') ? (int)XT_G1_256 : (int)XT_G1_128;
+  }();
+  return t;
+}
+static void try_gemm1x1(Ctx& c, const std::string& wname, GemmArgs& g) {
+  if (!gemm1x1_tile() || g.ks != 1 || g.Hout * g.Wout != 256 || g.s0 || g.sk > 1 || !gemm1x1_ok(g)) return;
+  auto it = c.e->xw.find(wname + "#g1");
+  if (it == c.e->xw.end()) return;
+  g.tile = gemm1x1_tile();
+  g.wpk = it->second.p;
+  g.cout_pad = it->second.cout_pad;
+  g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
+}
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
@@ -733,6 +784,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     // 8x8 layers: M x N has fewer tiles than the chip has CUs and K is thousands deep -> split K over 8 workgroups per
     // tile and reduce in a second, tiny launch.  The decision depends on the layer shape only (never on the batch), so
     // an image's result does not depend on what it is batched with.
+    if (ks == 1 && !sc0) try_gemm1x1(c, wname, g);
     const int sk = splitk_factor(g);
     if (sk > 1) {
       g.sk = sk;
@@ -1041,6 +1093,7 @@ int qkv_planes_conv(Ctx& c, const Act& x, const std::string& wname, const std::s
   if (heads == 1) { g.v_mod = 3 * C; g.v_off = 2 * C; g.v_dh = C; }
   else { g.v_mod = 3 * Dh; g.v_off = 2 * Dh; g.v_dh = Dh; }
   if (!g.bias) return fail(ASYRP_EKEY, "missing bias " + bname);
+  try_gemm1x1(c, wname, g);
   return run_gemm(c, g);
 }
 int attention_planes(Ctx& c, const QkvPlanes& pl, int C, int T, int heads, float scale, float* out /*[B][T][C]*/) {
@@ -1990,6 +2043,7 @@ int asyrp_finalize_params(asyrp_engine* e) {
             std::copy(wt.begin(), wt.end(), w3.begin() + (size_t)t * cout * cin);
           }
           TRY(pack_x3(e, ap + ".qkv.weight", w3, 3 * cout, cin, 1));
+          if (cin % 64 == 0) TRY(pack_g1(e, ap + ".qkv.weight", w3, 3 * cout, cin));
         }
       } else if (ends_with(p, ".k") || ends_with(p, ".v")) {
         continue;
@@ -1997,6 +2051,7 @@ int asyrp_finalize_params(asyrp_engine* e) {
         if (isd(s.key)) {
           TRY(upload(e, s.key, pack_conv(v, cout, cin, k)));
           if (e->math == MATH_F16X3) TRY(pack_x3(e, s.key, v, cout, cin, k));
+          if (e->math == MATH_F16X3 && k == 1 && cin % 64 == 0) TRY(pack_g1(e, s.key, v, cout, cin));   // gemm1x1.hip
           // convolutions applied to a nearest-x2 up-sampled tensor: the four phase-collapsed 2x2 images (polyphase form)
           if (e->math == MATH_F16X3 && k == 3 && cin % 32 == 0 && is_upsampled_conv(e, s.key)) TRY(pack_x3_up(e, s.key, v, cout, cin));
           // the UNet's last conv (conv_out / out.2): a second image with the 9 taps folded into N for conv_out.hip
@@ -2682,6 +2737,16 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
       g.wpk = xpu; g.w_phase = (long long)ph * 2;
       g.alpha = 1.0f / (ps * f16x3_act_scale());
     }
+    if (tile == XT_G1_256 || tile == XT_G1_128) {   // gemm1x1.hip: its fragment-major weight image
+      if (!gemm1x1_ok(g)) {
+        for (void* p : tmp) (void)hipFree(p);
+        return fail(ASYRP_EINVAL, "shape not covered by the 1x1 kernel (1x1, stride 1, Cin % 64 == 0, concat split % 32 == 0)");
+      }
+      float* xg;
+      TRY(dalloc((gemm1x1_packed_halfs(Cout, Cin) + 1) / 2, &xg));
+      HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
+      g.wpk = xg;
+    }
     if (tile == 13) {   // the taps-in-N kernel of the UNet's last conv (conv_out.hip): its own weight image
       std::vector<float> w1((size_t)9 * Cout * Cin);
       for (int co = 0; co < Cout; ++co)
@@ -2759,6 +2824,16 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
   g.bias = bias; g.out = yo; g.ldo = Cout; g.o_zo = (long long)HW * Cout; g.ZI = 1; g.Z = B;
   g.math = MATH_F16X3; g.tile = tile; g.wpk = xp; g.cout_pad = ((Cout + 127) / 128) * 128;
   g.alpha = 1.0f / (wscale * f16x3_act_scale());
+  if (tile == XT_G1_256 || tile == XT_G1_128) {
+    if (!gemm1x1_ok(g)) {
+      for (void* p : tmp) (void)hipFree(p);
+      return fail(ASYRP_EINVAL, "shape not covered by the 1x1 kernel");
+    }
+    float* xg;
+    TRY(dalloc((gemm1x1_packed_halfs(Cout, Cin) + 1) / 2, &xg));
+    HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
+    g.wpk = xg;
+  }
   const int nblk = gemm_mblocks(g);
   TRY(dalloc((size_t)B * nblk * Cout * 4, &st));
   g.stats = reinterpret_cast<double*>(st);
@@ -2918,6 +2993,13 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
         HIPCHK(launch_pack_f16x3(w + (size_t)q * Cout * Cin, reinterpret_cast<char*>(xpu) + (size_t)q * ph * 2, Cout, Cin, 2, wscale, s));
       g.poly = 1; g.ups = 0; g.Hout = H; g.Wout = W; g.tile = 0; g.wpk = xpu; g.w_phase = (long long)ph * 2;
     }
+    if (tile == XT_G1_256 || tile == XT_G1_128) {   // gemm1x1.hip
+      if (!gemm1x1_ok(g)) return fail(ASYRP_EINVAL, "shape not covered by the 1x1 kernel");
+      float* xg;
+      TRY(dalloc((gemm1x1_packed_halfs(Cout, Cin) + 1) / 2, &xg, 0.f, 13));
+      HIPCHK(launch_gemm1x1_pack(w, xg, Cout, Cin, wscale, s));
+      g.wpk = xg;
+    }
   }
   const int sk = (tile == 0) ? splitk_factor(g) : 1;   // as the engine does when it picks the tile itself
   if (sk > 1) {
@@ -2985,6 +3067,47 @@ int asyrp_op_attention_phases(int device, int B, int C, int T, int heads, int np
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(qkv); (void)hipFree(h); (void)hipFree(l); (void)hipFree(vh); (void)hipFree(vl); (void)hipFree(out); (void)hipFree(dbg);
   if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "attention phases run failed");
+  *ms_out = ms / iters;
+  return 0;
+}
+
+// phase stamps of gemm1x1_k32_kernel (per wave: start, prologue done, K loop done, end; 100 MHz s_memrealtime)
+int asyrp_op_gemm1x1_phases(int device, int B, int H, int Cin, int Cout, int prologue, int np, int tile, int iters, float* ms_out,
+                            unsigned long long* stamps_host, void* stream) {
+  HIPCHK(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * H, bm = (tile == XT_G1_256) ? 256 : 128;
+  const size_t nwave = (size_t)B * ((HW + bm - 1) / bm) * ((Cout + 127) / 128) * (bm / 32);
+  float *a, *w, *o, *sc, *sh; void* xg; unsigned long long* dbg;
+  HIPCHK(hipMalloc(&a, (size_t)B * HW * Cin * 4)); HIPCHK(hipMalloc(&w, (size_t)Cout * Cin * 4)); HIPCHK(hipMalloc(&o, (size_t)B * HW * Cout * 4));
+  HIPCHK(hipMalloc(&sc, (size_t)B * Cin * 4)); HIPCHK(hipMalloc(&sh, (size_t)B * Cin * 4)); HIPCHK(hipMalloc(&xg, gemm1x1_packed_halfs(Cout, Cin) * 2));
+  HIPCHK(hipMalloc(&dbg, nwave * 32));
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, a, (long long)B * HW * Cin, 3u, 2.0f);
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, w, (long long)Cout * Cin, 4u, 0.1f);
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(64), dim3(256), 0, s, sc, (long long)B * Cin, 5u, 1.0f);
+  hipLaunchKernelGGL(fill_hash_kernel, dim3(64), dim3(256), 0, s, sh, (long long)B * Cin, 6u, 1.0f);
+  HIPCHK(launch_gemm1x1_pack(w, xg, Cout, Cin, 8192.f, s));
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.a0 = a; g.c0 = Cin; g.lda0 = Cin; g.a0_zo = (long long)HW * Cin;
+  g.Hin = H; g.Win = H; g.Hout = H; g.Wout = H; g.Cin = Cin; g.Cout = Cout; g.ks = 1; g.stride = 1;
+  if (prologue) { g.pscale = sc; g.pshift = sh; g.silu = prologue > 1; }
+  g.alpha = 1.f / 8192.f; g.out = o; g.ldo = Cout; g.o_zo = (long long)HW * Cout; g.ZI = 1; g.Z = B;
+  g.math = MATH_F16X3; g.np = np; g.tile = tile; g.wpk = xg; g.cout_pad = ((Cout + 127) / 128) * 128;
+  g.part = reinterpret_cast<float*>(dbg);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  hipError_t le = launch_gemm1x1(g, s);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_gemm1x1(g, s);
+  (void)hipEventRecord(e1, s);
+  hipError_t se = hipStreamSynchronize(s);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (stamps_host) (void)hipMemcpy(stamps_host, dbg, nwave * 32, hipMemcpyDeviceToHost);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(w); (void)hipFree(o); (void)hipFree(sc); (void)hipFree(sh); (void)hipFree(xg); (void)hipFree(dbg);
+  if (le != hipSuccess || se != hipSuccess) return fail(ASYRP_EHIP, "gemm1x1 phases run failed");
   *ms_out = ms / iters;
   return 0;
 }

@@ -75,6 +75,8 @@ enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4,
        XT_64x128K32S2 = 10 /* stride 2 (DDPM Downsample): 4 x 16 output patch, 8 waves of 64 pixels x 16 channels */,
        XT_256x128K32UP = 11 /* polyphase form of the main tile: nearest x2 + 3x3 as four 2x2-tap phases on the source grid */,
        XT_256x128K32Q = 14 /* quad form for the 8 x 8 layers: four images per workgroup, split-K (GemmArgs.sk / part) */,
+       XT_G1_256 = 15 /* gemm1x1.hip: barrier-free 1x1 kernel, 256 pixels x 128 channels, 8 waves; wpk = its fragment-major image */,
+       XT_G1_128 = 16 /* the same with 128 pixels x 128 channels, 4 waves, two workgroups per CU */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
@@ -87,6 +89,12 @@ size_t f16x3_packed_halfs(int cout, int cin, int ks);
 hipError_t launch_pack_f16x3(const float* w_dev /*[Cout][Cin][ks][ks]*/, void* dst, int cout, int cin, int ks,
                              float wscale, hipStream_t s);
 float f16x3_act_scale();
+// gemm1x1.hip: 1x1 convolutions without LDS staging; weight image [ceil(Cout/16)][Cin/32][hi|lo][64 lanes][8] halfs (MFMA fragment order)
+size_t gemm1x1_packed_halfs(int cout, int cin);
+hipError_t launch_gemm1x1_pack(const float* w_dev /*[Cout][Cin]*/, void* dst, int cout, int cin, float wscale, hipStream_t s);
+bool xcd_map_enabled();                        // ASYRP_XCD_MAP != 0 (conv_f16x3.hip)
+bool gemm1x1_ok(const GemmArgs& a);           // shape / alignment rules of the kernel (tile and wpk not looked at)
+hipError_t launch_gemm1x1(const GemmArgs& a, hipStream_t s);   // a.tile = XT_G1_256 | XT_G1_128, a.wpk = the image above
 // algorithmic work of one launch (2*M*N*K flops; A read once + out written once + weights once)
 void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 

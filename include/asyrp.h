@@ -232,7 +232,8 @@ int asyrp_profile_enable(asyrp_engine* e, int on);
  *                             11=the polyphase form of tile 7 for "nearest x2 then 3x3" (Upsample.conv / ResBlock(up=True)): four
  *                             phase-collapsed 2x2-tap convolutions on the source grid, 4/9 of the products; its FLOPs are
  *                             counted as issued (4 taps), 12=256x32, 14=the quad form of tile 7 for the 8x8-pixel layers: four images per
- *                             workgroup, split-K with a fixed-order reduce),
+ *                             workgroup, split-K with a fixed-order reduce, 15 / 16 = the barrier-free 1x1 kernel of csrc/gemm1x1.hip
+ *                             (256 / 128 pixels x 128 channels; weights in MFMA fragment order, no LDS staging)),
  *   its accumulated event time (ms), launch count, algorithmic FLOPs (2*M*N*K) and algorithmic bytes
  *   (input read once + output written once + weights once); all_ms / all_flops cover every variant.
  * Resets the record. */
@@ -253,6 +254,7 @@ int asyrp_profile_table(asyrp_engine* e, int max_rows, int* variants, double* ms
  *   conv_math: enum asyrp_conv_math; tile: 0 = the launcher's own choice, else force one tile shape of that
  *   kernel family so every compiled variant can be parity-tested (tile 7 falls back to tile 6 when Cin % 32 != 0);
  *   tile 11 = the polyphase form for upsample != 0 (3x3, Cin % 32 == 0, no residual);
+ *   tiles 15 / 16 = the 1x1 kernel of csrc/gemm1x1.hip (1x1, Cin % 64 == 0, concat split % 32 == 0; ASYRP_EINVAL otherwise);
  *   tile 13 = the taps-in-N kernel of the UNet's last
  *   convolution (csrc/conv_out.hip: 3x3, stride 1, Cout*9 <= 32, GroupNorm + SiLU prologue required). */
 int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
@@ -293,6 +295,8 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
  * 5 end (scripts/attn_phases.py). */
 int asyrp_op_attention_phases(int device, int B, int C, int T, int heads, int np, int iters, float* ms_out,
                               unsigned long long* stamps_host, void* stream);
+int asyrp_op_gemm1x1_phases(int device, int B, int H, int Cin, int Cout, int prologue, int np, int tile, int iters, float* ms_out,
+                            unsigned long long* stamps_host, void* stream);
 #endif
 
 #ifdef __cplusplus

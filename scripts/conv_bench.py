@@ -115,8 +115,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "onebyone":  # 1x1 GEMMs of the attention blocks: tile sweep (2 = 128x128, 3 = 64x128, 4 = 64x64, 1 = 256x128)
         print(f"-- B={B}: 1x1 GEMMs at 16x16 / 8x8, us per launch by tile (0 = launcher's choice)")
-        for (H, Ci, Co, pro) in ((16, 512, 1536, 1), (16, 512, 512, 0), (8, 512, 1536, 1), (8, 512, 512, 0), (8, 1024, 512, 0), (32, 512, 1536, 1), (32, 512, 512, 0)):
-            tiles = (0, 1, 2, 3, 4)
+        for (H, Ci, Co, pro) in ((16, 512, 1536, 1), (16, 512, 512, 0), (16, 768, 256, 0), (8, 512, 1536, 1), (8, 512, 512, 0), (8, 1024, 512, 0), (32, 512, 1536, 1), (32, 512, 512, 0),
+                                 (32, 512, 256, 0), (64, 384, 128, 0), (256, 256, 128, 0)):
+            tiles = (0, 1, 2, 3, 4, 15, 16)      # 15 / 16: the barrier-free kernel of gemm1x1.hip (256 / 128 pixels)
             r = {t: [] for t in tiles}
             for rnd in range(5):
                 for t in tiles:

@@ -480,3 +480,68 @@ def test_quad_form_8x8_layers(B, C0, C1, Cout, pro, res, math):
     else:
         err = float((got - want).abs().max())
         assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,pro,res", [(2, 512, 0, 1536, 16, 16, True, False), (3, 256, 0, 256, 16, 16, False, True),
+                                                      (2, 160, 96, 200, 20, 12, True, True), (1, 64, 0, 24, 8, 8, False, False),
+                                                      (2, 128, 64, 128, 40, 24, True, False)])
+def test_barrier_free_1x1_kernel(tile, B, C0, C1, Cout, H, W, pro, res, math):
+    """gemm1x1.hip (weights in MFMA fragment order, activations converted in registers, no LDS staging): q|k|v-sized, proj_out with
+    residual, a concat with a ragged pixel tile and a channel count that is not a multiple of 16, an 8 x 8 image (partial M tile)."""
+    x0 = hash_normal(f"g1.x0.{B}.{C0}", (B, C0, H, W))
+    x1 = hash_normal(f"g1.x1.{B}.{C1}", (B, C1, H, W)) if C1 else None
+    Cin = C0 + C1
+    w = hash_uniform(f"g1.w.{Cin}.{Cout}", (Cout, Cin, 1, 1), -1, 1) / Cin ** 0.5
+    b = 0.1 * hash_uniform(f"g1.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform(f"g1.g.{Cin}", (Cin,)), 0.1 * hash_uniform(f"g1.be.{Cin}", (Cin,))) if pro else None
+    r = hash_normal(f"g1.r.{B}.{Cout}", (B, Cout, H, W)) if res else None
+    ca = hash_normal(f"g1.ca.{B}.{Cout}", (B, Cout))
+    kw = dict(x1=x1, gn=gn, silu=pro and Cout != 1536, residual=r, chan_add=ca)
+    got = hip_conv(x0, w, b, math=math, tile=tile, **kw)
+    want = ref_conv(x0, w, b, **kw)
+    if math == "f16x3":
+        assert_close(got, want, what="1x1 kernel", **TIGHT)
+        i = B - 1
+        alone = hip_conv(x0[i:i + 1], w, b, x1=None if x1 is None else x1[i:i + 1], gn=gn, silu=kw["silu"],
+                         residual=None if r is None else r[i:i + 1], chan_add=ca[i:i + 1], math=math, tile=tile)
+        assert torch.equal(alone[0], got[i]), "1x1 kernel: result depends on the batch"
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+def test_barrier_free_1x1_kernel_refuses_other_shapes():
+    from asyrp_official_amd import _lib
+    x, w, b = _mk(1, 96, 64, 16, 1, "g1.bad")          # Cin % 64 != 0
+    with pytest.raises(_lib.AsyrpError):
+        hip_conv(x, w, b, tile=15)
+    x, w, b = _mk(1, 64, 64, 16, 3, "g1.bad3")         # 3x3
+    with pytest.raises(_lib.AsyrpError):
+        hip_conv(x, w, b, tile=16)
+
+
+@pytest.mark.parametrize("tile,H,W,Cin,Cout,offset", [(15, 16, 16, 64, 128, 5.0), (16, 16, 16, 128, 96, 0.0), (15, 20, 36, 64, 160, 0.0),
+                                                     (16, 20, 36, 64, 160, 30.0)])
+def test_barrier_free_1x1_kernel_statistics_epilogue(tile, H, W, Cin, Cout, offset):
+    """GroupNorm partials of the 1x1 kernel's epilogue (proj_out feeds the next block's norm1) incl. a ragged last pixel tile."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    B = 2
+    x = hash_normal(f"g1st.x.{tile}.{Cin}", (B, Cin, H, W))
+    w = hash_uniform(f"g1st.w.{tile}.{Cin}", (Cout, Cin, 1, 1), -1, 1) / Cin ** 0.5
+    b = 0.1 * hash_uniform(f"g1st.b.{tile}", (Cout,)) + offset
+    gam, bet = 1 + 0.1 * hash_uniform("g1st.g", (Cout,)), 0.1 * hash_uniform("g1st.be", (Cout,))
+    d = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = map(d, (x, w, b, gam, bet))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    sc, sh = torch.empty((B, Cout), device="cuda"), torch.empty((B, Cout), device="cuda")
+    _lib.check(lib.asyrp_op_conv2d_stats(0, _p(xd), Cin, B, H, W, _p(wd), _p(bd), Cout, 1, tile, _p(gd), _p(bed), 1e-6,
+                                         _p(y), _p(sc), _p(sh), None))
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x, w, b)
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-4, atol=2e-5 * max(1.0, offset))
+    got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
+    assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
