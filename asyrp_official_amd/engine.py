@@ -286,7 +286,7 @@ class Engine:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
                     12: (4, 1, 2, 1)}.get(tid, (0,) * 4)
             if tid in (15, 16):                 # gemm1x1.hip: the barrier-free 1x1 kernel (8 / 4 waves)
-                return "f16x3", "asyrp::gemm1x1_k32_kernel<WM=%d>" % (4 if tid == 15 else 2)
+                return "f16x3", "asyrp::gemm1x1_k32_kernel (WM=%d)" % (4 if tid == 15 else 2)
             if tid in (7, 8, 9, 10, 11, 14):    # the v_mfma_f32_16x16x32_f16 kernels: 256- / 128- / 64-pixel forms, stride 2, polyphase x2, quad 8x8
                 return "f16x3", "asyrp::igemm_f16x3_k32_kernel<asyrp::K32Cfg<%s>>" % {7: "8, 2", 8: "8, 4", 9: "8, 8, 8", 10: "8, 8, 16, 2",
                                                                                      11: "8, 2, 16, 1, 2", 14: "8, 2, 16, 1, 3, true"}[tid]
