@@ -542,7 +542,32 @@ hipError_t launch_gn_partial(const float* a, int lda, long long a_z, int HW, int
 }
 
 // one WAVE per (group, image): lane-strided accumulation in a fixed order + a fixed butterfly => deterministic and
-// batch-invariant; no LDS, no barriers (the kernel is launched 220 times per UNet evaluation: its cost is its latency)
+// batch-invariant; no LDS, no barriers.  The kernel runs 6 460 times per edit and its cost is its latency, so the (channel, block)
+// items of a group are ONE flat list dealt to the lanes with the channel index fastest (a wave's load covers whole
+// 16-B x channels-per-group runs) and GF2_U independent loads are in flight per lane before the first add: 7.3 -> 5.4 us per
+// launch (profiles/rd3s_*; before, lanes strode over blocks only with one dependent load per step -- a 1024-channel concat at
+// 16 x 16 kept 2 of 64 lanes busy for 32 serial steps).  The launches of the 256 x 256 level read 17-34 MB of partials and stay at
+// 7-15 us; a whole workgroup per group changed nothing there (9.2 us either way: they run at the rate of those reads).
+constexpr int GF2_U = 8;
+__device__ __forceinline__ void gf2_accum(const double* __restrict__ src, int nblk, int Cs, int n, int c_first, int nch, int lane,
+                                          double& a, double& b) {
+  const int items = nch * nblk;                          // item i = (block k = i / nch, channel j = i % nch)
+  const double2* __restrict__ base = reinterpret_cast<const double2*>(src) + (size_t)n * nblk * Cs + c_first;
+  for (int i0 = 0; i0 < items; i0 += 64 * GF2_U) {
+    double2 v[GF2_U];
+#pragma unroll
+    for (int u = 0; u < GF2_U; ++u) {
+      const int i = min(i0 + u * 64 + lane, items - 1);  // clamped: every lane issues the same loads, the surplus is dropped below
+      const int k = i / nch, j = i - k * nch;
+      v[u] = base[(size_t)k * Cs + j];
+    }
+#pragma unroll
+    for (int u = 0; u < GF2_U; ++u) {
+      if (i0 + u * 64 + lane < items) { a += v[u].x; b += v[u].y; }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) gn_finalize2_kernel(const GnFin2Args p) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);     // (image, group) pair
@@ -550,19 +575,11 @@ __global__ void __launch_bounds__(256) gn_finalize2_kernel(const GnFin2Args p) {
   const int n = item >> 5, g = item & 31;
   const int C = p.C0 + p.C1, cg = C / 32;
   double a = 0.0, b = 0.0;
-  // items of this group: (channel j in [0,cg), block k) of the source the channel lives in
-  for (int j = 0; j < cg; ++j) {
-    const int c = g * cg + j;
-    const double* src;
-    int nblk, Cs, cl;
-    if (c < p.C0) { src = p.p0; nblk = p.nblk0; Cs = p.C0; cl = c; }
-    else { src = p.p1; nblk = p.nblk1; Cs = p.C1; cl = c - p.C0; }
-    for (int k = lane; k < nblk; k += 64) {
-      const double* q = src + (((size_t)n * nblk + k) * Cs + cl) * 2;
-      a += q[0];
-      b += q[1];
-    }
-  }
+  // the group's channels [g cg, (g + 1) cg) may straddle the two sources of a concat: source 0 first, then source 1
+  const int c_lo = g * cg, c_hi = c_lo + cg;
+  const int n0 = max(0, min(c_hi, p.C0) - c_lo);
+  if (n0 > 0) gf2_accum(p.p0, p.nblk0, p.C0, n, c_lo, n0, lane, a, b);
+  if (n0 < cg) gf2_accum(p.p1, p.nblk1, p.C1, n, max(c_lo, p.C0) - p.C0, cg - n0, lane, a, b);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     a += __shfl_xor(a, o);
