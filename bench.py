@@ -170,6 +170,38 @@ def _self_launch(n):
     os.execvpe(cmd[0], cmd, env)
 
 
+def paste_traffic(res, tpath, lib_path, dt, steps):
+    """HBM traffic per kernel family into a result line.  PMC counters cannot be read inline; the committed rocprofv3 --pmc passes
+    of this command (scripts/gpu_traffic_families.sh -> profiles/traffic_families_<config>_b<B>_<math>.json) are reported per launch
+    -- but only when they were taken on the library that is loaded now (sha256 stamp): a stale measurement is refused, never pasted.
+    dt = seconds of the timed region, steps = its step count (kernel_families carries each family's share of the region and its
+    launches per step)."""
+    import hashlib
+    if not os.path.exists(tpath):
+        return
+    tr = json.load(open(tpath))
+    sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
+    if tr.get("library_sha256") != sha:
+        res["roofline"]["traffic_note"] = (f"{os.path.basename(tpath)} was measured on another build of the library "
+                                           f"(sha256 {tr.get('library_sha256', '?')[:12]} != {sha[:12]}): not reported")
+        return
+    fams_t = tr["families"]
+    hit = fams_t.get(res["roofline"]["kernel"])
+    if hit:
+        res["roofline"]["traffic"] = hit["hbm_bytes_per_launch"]
+        res["roofline"]["traffic_note"] = (f"HBM bytes per launch = 1024 x (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes "
+                                           f"over every launch of one edit on this library build ({os.path.basename(tpath)}); "
+                                           "compare with algorithmic_bytes_per_launch")
+    for fm in res.get("kernel_families", []):
+        key = fm["kernel"].split(" (")[0]
+        ht = fams_t.get(key)
+        if ht and fm["launches_per_step"]:
+            sec_per_launch = fm["share_of_step"] * dt / steps / fm["launches_per_step"]
+            fm["counter_bytes_per_launch"] = ht["hbm_bytes_per_launch"]
+            fm["counter_GBps"] = ht["hbm_bytes_per_launch"] / sec_per_launch / 1e9
+            fm["counter_frac_of_hbm_peak"] = fm["counter_GBps"] / (HBM_PEAK_TBS * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,34 +416,11 @@ def main():
                                              "launches_per_step": sum(r["launches"] for r in att) / a.steps,
                                              "share_of_step": ms_ * 1e-3 / dt,
                                              "kernels": sorted({r["kernel"] for r in att})}
-        # HBM traffic per kernel family: PMC counters cannot be read inline; the committed rocprofv3 --pmc passes of this command
-        # (scripts/gpu_traffic_families.sh -> profiles/traffic_families_<config>_<math>.json) are reported per launch -- but only
-        # when they were taken on THIS library (sha256 stamp): a stale measurement is refused, never pasted
-        tpath = os.path.join(ROOT, "profiles", f"traffic_families_{a.config}_b{B}_{a.conv_math}.json")
-        if "roofline" in res and os.path.exists(tpath):
-            import hashlib
+        # HBM traffic per kernel family (see paste_traffic): only a measurement taken on THIS library build is reported
+        if "roofline" in res:
             from asyrp_official_amd import _lib
-            tr = json.load(open(tpath))
-            sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
-            if tr.get("library_sha256") != sha:
-                res["roofline"]["traffic_note"] = (f"{os.path.basename(tpath)} was measured on another build of the library "
-                                                   f"(sha256 {tr.get('library_sha256', '?')[:12]} != {sha[:12]}): not reported")
-            else:
-                fams_t = tr["families"]
-                hit = fams_t.get(res["roofline"]["kernel"])
-                if hit:
-                    res["roofline"]["traffic"] = hit["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_note"] = (f"HBM bytes per launch = 1024 x (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc passes "
-                                                       f"over every launch of one edit on this library build ({os.path.basename(tpath)}); "
-                                                       "compare with algorithmic_bytes_per_launch")
-                for fm in res.get("kernel_families", []):
-                    key = fm["kernel"].split(" (")[0]
-                    ht = fams_t.get(key)
-                    if ht and fm["launches_per_step"]:
-                        sec_per_launch = fm["share_of_step"] * dt / a.steps / fm["launches_per_step"]
-                        fm["counter_bytes_per_launch"] = ht["hbm_bytes_per_launch"]
-                        fm["counter_GBps"] = ht["hbm_bytes_per_launch"] / sec_per_launch / 1e9
-                        fm["counter_frac_of_hbm_peak"] = fm["counter_GBps"] / (HBM_PEAK_TBS * 1e3)
+            paste_traffic(res, os.path.join(ROOT, "profiles", f"traffic_families_{a.config}_b{B}_{a.conv_math}.json"), _lib.LIB_PATH,
+                          dt, a.steps)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], cpu_chk = cpu_baseline(cpu_sd, betas, family, learn_sigma,
                                                          x_check=x0_cpu[chk_rows] if gpu_check is not None else None)

@@ -282,3 +282,45 @@ def test_bench_cpu_baseline_uses_the_reference_when_importable():
     assert kind2 == "port"
     want = step2(x, one * 0.0, one * 25.0, eta=0)[0]
     assert torch.allclose(got, want, rtol=1e-5, atol=2e-6)
+
+
+def test_bench_reports_counter_traffic_only_for_the_loaded_library_build(tmp_path):
+    """bench.py pastes the committed rocprofv3 --pmc traffic into a line only when the file's sha256 stamp equals the library
+    it is running on; a stale file is refused with a note."""
+    import hashlib
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(b"library build A")
+    main = "asyrp::igemm_f16x3_k32_kernel<asyrp::K32Cfg<8, 2>>"
+    fams = {main: {"hbm_bytes_per_launch": 1.5e9}, "asyrp::attn_planes_kernel": {"hbm_bytes_per_launch": 6e7}}
+    tfile = tmp_path / "traffic.json"
+
+    def line():
+        return {"roofline": {"kernel": main, "traffic": None},
+                "kernel_families": [{"kernel": main, "launches_per_step": 4000.0, "share_of_step": 0.8},
+                                    {"kernel": "asyrp::attn_planes_kernel (T=256)", "launches_per_step": 400.0, "share_of_step": 0.004},
+                                    {"kernel": "asyrp::conv_out_kernel (Cout=3)", "launches_per_step": 99.0, "share_of_step": 0.01}]}
+
+    # stamp of another build: nothing is pasted
+    tfile.write_text(json.dumps({"library_sha256": hashlib.sha256(b"library build B").hexdigest(), "families": fams}))
+    r = line()
+    bench.paste_traffic(r, str(tfile), str(lib), dt=8.0, steps=2)
+    assert r["roofline"]["traffic"] is None and "another build" in r["roofline"]["traffic_note"]
+    assert all("counter_GBps" not in f for f in r["kernel_families"])
+    # matching stamp: bytes per launch of the dominant kernel, GB/s per family from this run's own launch durations
+    tfile.write_text(json.dumps({"library_sha256": hashlib.sha256(b"library build A").hexdigest(), "families": fams}))
+    r = line()
+    bench.paste_traffic(r, str(tfile), str(lib), dt=8.0, steps=2)
+    assert r["roofline"]["traffic"] == 1.5e9
+    sec = 0.8 * 8.0 / 2 / 4000.0                                  # 0.8 of the 8-second region, 2 steps x 4000 launches
+    assert abs(r["kernel_families"][0]["counter_GBps"] - 1.5e9 / sec / 1e9) < 1e-6
+    assert "counter_GBps" in r["kernel_families"][1]              # "name (T=256)" is keyed by the kernel name
+    assert "counter_GBps" not in r["kernel_families"][2]          # no counters for this family in the file: left out, not guessed
+    # no file at all: untouched
+    r = line()
+    bench.paste_traffic(r, str(tmp_path / "missing.json"), str(lib), dt=8.0, steps=2)
+    assert r["roofline"]["traffic"] is None and "traffic_note" not in r["roofline"]
