@@ -788,7 +788,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     const int sk = splitk_factor(g);
     if (sk > 1) {
       g.sk = sk;
-      g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+      g.tile = splitk_tile(g);
       TRY(c.e->pool.get((size_t)sk * c.B * Ho * Wo * Cout, &g.part));
     }
     if (want_stats) {   // the output will be group-normalised: its statistics come out of this launch's epilogue
@@ -2777,7 +2777,7 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
   const int sk = (tile == 0 && g.math == MATH_F16X3) ? splitk_factor(g) : 1;
   if (sk > 1) {
     g.sk = sk;
-    g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+    g.tile = splitk_tile(g);
     TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part));
   }
   hipError_t le = launch_gemm(g, s);
@@ -3004,7 +3004,7 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   const int sk = (tile == 0) ? splitk_factor(g) : 1;   // as the engine does when it picks the tile itself
   if (sk > 1) {
     g.sk = sk;
-    g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+    g.tile = splitk_tile(g);
     TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part, 0.f, 11));
   }
   auto once = [&]() -> hipError_t {

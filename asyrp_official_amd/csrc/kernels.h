@@ -124,6 +124,8 @@ hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int splitk_stat_blocks(int HW);
 int splitk_factor(const GemmArgs& a);   // 1 = none; a function of the LAYER SHAPE only (batch-invariant results)
 bool splitk_quad(const GemmArgs& a);    // the split launch runs on the quad form (XT_256x128K32Q) instead of the 64x64 tile
+bool splitk16(const GemmArgs& a);       // 16 x 16 maps: 2-way split on the 128-pixel K32 form (round 4)
+int splitk_tile(const GemmArgs& a);     // XT_* a split launch of `a` runs on (quad form, a plain K32 form, or the 64x64 tile)
 int gemm_main_tile();
 bool gemm_can_fuse_shortcut(const GemmArgs& a);   // true when launch_gemm_f16x3 would run `a` (with s0/Cin2 set) on the fusing tile
 int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats

@@ -364,7 +364,7 @@ def main():
                                         if world > 1 and backend == "nccl" else None),
                        # A/B switches read by the library from the environment: a non-default kernel choice can never be
                        # benchmarked silently
-                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1")},
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16")},
                        "conv_math": a.conv_math},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above

@@ -545,3 +545,34 @@ def test_barrier_free_1x1_kernel_statistics_epilogue(tile, H, W, Cin, Cout, offs
     got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
     want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("B,C0,C1,Cout,pro,res", [(2, 512, 0, 512, True, True), (1, 512, 512, 512, True, False), (3, 256, 0, 512, False, False),
+                                                   (2, 512, 256, 160, True, True)])
+def test_splitk_16x16_layers(B, C0, C1, Cout, pro, res, math):
+    """The launcher's choice for 3x3 layers on 16 x 16 maps (round 4): the 128-pixel K32 form with the K range split two ways and a
+    fixed-order reduce (bias / timestep vector / residual / GroupNorm partials in the reduce) -- concat input, ragged N tile,
+    against the fp32 reference, against the single-pass form (tile 8), and image-alone == image-in-batch bit for bit."""
+    x0 = hash_normal(f"sk16.x0.{B}.{C0}", (B, C0, 16, 16))
+    x1 = hash_normal(f"sk16.x1.{B}.{C1}", (B, C1, 16, 16)) if C1 else None
+    Cin = C0 + C1
+    w = hash_uniform(f"sk16.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"sk16.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform(f"sk16.g.{Cin}", (Cin,)), 0.1 * hash_uniform(f"sk16.be.{Cin}", (Cin,))) if pro else None
+    r = hash_normal(f"sk16.r.{B}.{Cout}", (B, Cout, 16, 16)) if res else None
+    ca = hash_normal(f"sk16.ca.{B}.{Cout}", (B, Cout))
+    kw = dict(x1=x1, gn=gn, silu=pro, residual=r, chan_add=ca)
+    got = hip_conv(x0, w, b, math=math, **kw)
+    want = ref_conv(x0, w, b, **kw)
+    if math == "f16x3":
+        assert_close(got, want, what="split-K 16x16", **TIGHT)
+        single = hip_conv(x0, w, b, math=math, tile=8, **kw)          # the same form without the split
+        assert_close(got, single, what="split-K vs single pass", rtol=1e-5, atol=2e-6)
+        i = B - 1
+        alone = hip_conv(x0[i:i + 1], w, b, x1=None if x1 is None else x1[i:i + 1], gn=gn, silu=pro,
+                         residual=None if r is None else r[i:i + 1], chan_add=ca[i:i + 1], math=math)
+        assert torch.equal(alone[0], got[i]), "split-K 16x16: result depends on the batch"
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
