@@ -1435,7 +1435,36 @@ int gemm_main_tile() { return XT_256x128W8; }
 // pre-summed biases vs two launches) and how the GroupNorm partial sums are partitioned (gemm_mblocks), so a
 // batch-dependent choice would make an image's bits depend on what it is batched or sharded with.
 constexpr int NOMINAL_Z = 32;   // BASELINE.json configs[1]: 32 images per GPU
+// Batch class (round 4).  The nominal batch is a property of the ENGINE (asyrp_config.nominal_batch, fixed at
+// asyrp_create; GemmArgs.nz; 0 = 32), never of the call, so an image's bits still do not depend on what it is batched with on that
+// engine.  The small class (nominal batch 1 or 2: single-image serving, the reference's bs_train = 1) keeps every 3x3 stride-1
+// layer with Cin % 32 == 0 on the K32 family -- 256-pixel form from 64 x 64 up, 128-pixel form at 32 x 32 and 16 x 16, the 8 x 8
+// patch form below -- and splits K until the launch offers >= 256 workgroups at the nominal batch (<= 8 ranges, whole K = 32
+// steps per range); no quad grouping.  Results across classes agree to fp32 rounding, like any two tile shapes.
+static int nominal_z(const GemmArgs& a) { return a.nz > 0 ? a.nz : NOMINAL_Z; }
+static bool is_vec(const GemmArgs& a);
+static bool k32_preferred();
+int small_class_tile(const GemmArgs& a) {   // 0: the default rules apply
+  if (nominal_z(a) > 2 || a.math != MATH_F16X3 || a.ks != 3 || a.stride != 1 || a.ups || a.abl || a.poly || a.rups) return 0;
+  if ((a.Cin & 31) || a.Cin < 32 || !is_vec(a) || !k32_preferred()) return 0;
+  const long long M = (long long)a.Hout * a.Wout;
+  if (M >= 4096) return XT_256x128K32;
+  if (M >= 256) return XT_128x128K32;
+  return (a.Hout == 8 && a.Wout == 8) ? XT_64x128K32 : 0;
+}
+int small_class_sk(const GemmArgs& a) {     // K ranges of a small-class launch of `a` WITHOUT a fused shortcut
+  const int t = small_class_tile(a);
+  if (!t) return 1;
+  const int bm = t == XT_256x128K32 ? 256 : (t == XT_128x128K32 ? 128 : 64), pw = bm >= 128 ? 16 : 8, ph = bm / pw;
+  const long long wgs = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw) * ((a.Cout + 127) / 128) * nominal_z(a);
+  int sk = 1;
+  while (sk < 8 && wgs * sk < 256) sk *= 2;
+  const int nch = a.Cin / XKC;
+  while (sk > 1 && (nch % (2 * sk)) != 0) sk /= 2;
+  return sk;
+}
 static int auto_tile_x(const GemmArgs& a) {
+  if (const int t = small_class_tile(a)) return t;
   if (a.stride == 2) return XT_64x128;
   const long long M = (long long)a.Hout * a.Wout;
   auto blocks = [&](int bm, int bn) {
@@ -1446,7 +1475,7 @@ static int auto_tile_x(const GemmArgs& a) {
       const int pw = bm >= 128 ? 16 : 8, ph = bm / pw;
       mt = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
     }
-    return mt * ((a.Cout + bn - 1) / bn) * NOMINAL_Z;
+    return mt * ((a.Cout + bn - 1) / bn) * nominal_z(a);
   };
   if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
@@ -1628,7 +1657,7 @@ constexpr int SKR_PIX = 8;    // pixels per reduce workgroup == pixels per stati
 
 int splitk_stat_blocks(int HW) { return (HW + SKR_PIX - 1) / SKR_PIX; }
 
-int splitk_factor(const GemmArgs& a) {
+static int splitk_factor_impl(const GemmArgs& a, bool allow16) {
   if (a.math != MATH_F16X3 || !a.wpk || a.ks != 3 || a.stride != 1 || a.ups || a.s0 || a.rups || a.abl) return 1;
   // measured (profiles/r01_conv_microbench_kb8_splitk.txt, B=32): 1024->512 @8x8 179 -> 134 us; 512->512 @8x8 no gain (91 us
   // either way: with 32 chunks a workgroup's fixed prologue/epilogue latency equals its share of the loop)
@@ -1637,25 +1666,33 @@ int splitk_factor(const GemmArgs& a) {
   // round 4: the 16 x 16 maps on the 128-pixel K32 form offer 2 x Cout/128 workgroups per image -- 256 at the nominal batch, one
   // per CU with two waves per SIMD (matrix pipe 32 % busy, half of the wave cycles parked: profiles/rd3_pmc_families_*) -- a 2-way K
   // split fills the second slot (ASYRP_SPLITK16=0: off).  Blocks with a fused 1x1 shortcut keep the single-pass form (a.s0 above).
-  if (splitk16(a)) return 2;
+  if (small_class_tile(a)) return small_class_sk(a);
+  if (allow16 && splitk16(a)) return 2;
   if (a.Hout * a.Wout > 64 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
   if (splitk_quad(a)) return 8;
   return a.Cin >= 1024 ? 8 : 1;
 }
+int splitk_factor(const GemmArgs& a) { return splitk_factor_impl(a, true); }
+// for the partial launches of a dual step's shared skip half (engine.hip conv1_shared): sharing is worth more than the 16 x 16 split
+int splitk_factor_shared(const GemmArgs& a) { return splitk_factor_impl(a, false); }
+// a block's 1x1 shortcut runs as its own launch (and enters the reduce as the residual) instead of being fused: the quad form, and
+// the small class whenever the unfused conv splits K
+bool splitk_unfused(const GemmArgs& a) { return splitk_quad(a) || (small_class_tile(a) && small_class_sk(a) > 1); }
 bool splitk16(const GemmArgs& a) {
   static const bool on = [] { const char* e = getenv("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
-  return on && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.rups && a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16 &&
+  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.rups && a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16 &&
          a.Cin >= 256 && (a.Cin % 64) == 0 && is_vec(a) && k32_preferred();
 }
 // the tile a split launch runs on (a function of the layer shape only, like the factor)
 int splitk_tile(const GemmArgs& a) {
+  if (const int t = small_class_tile(a)) return t;
   if (splitk_quad(a)) return XT_256x128K32Q;
   if (splitk16(a)) return XT_128x128K32;
   return XT_64x64;
 }
 bool splitk_quad(const GemmArgs& a) {
   static const bool on = [] { const char* e = getenv("ASYRP_QUAD8"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
-  return on && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
+  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
          (a.Cin % 256) == 0 && a.a0_zo == 64LL * a.lda0 && (!a.a1 || a.a1_zo == 64LL * a.lda1);
 }
 

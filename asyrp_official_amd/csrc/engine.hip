@@ -696,6 +696,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   TRY(new_act(c, Cout, Ho, Wo, out));
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.nz = c.e->cfg.nominal_batch;
   g.a0 = x0.p; g.c0 = x0.C; g.lda0 = x0.C; g.a0_zo = x0.per_image();
   if (x1) { g.a1 = x1->p; g.c1 = x1->C; g.lda1 = x1->C; g.a1_zo = x1->per_image(); }
   g.Hin = Hin; g.Win = Win; g.Hout = Ho; g.Wout = Wo;
@@ -733,7 +734,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
       const float* fb = P(c, bname + "#sc");
       // 8 x 8 layers: the quad form (four images per workgroup, split-K) without the fusion beats the fused 64-pixel form --
       // 46 us + a 1x1 launch against 150 us -- so these blocks take the two-launch form (the shortcut enters the reduce as the residual)
-      if (fit != c.e->xw.end() && fb && !resid && !splitk_quad(g)) {
+      if (fit != c.e->xw.end() && fb && !resid && !splitk_unfused(g)) {
         GemmArgs t = g;
         t.s0 = sc0->p; t.sc0 = sc0->C; t.lds0 = sc0->C; t.s0_zo = sc0->per_image();
         if (sc1) { t.s1 = sc1->p; t.sc1 = sc1->C; t.lds1 = sc1->C; t.s1_zo = sc1->per_image(); }
@@ -904,6 +905,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   const int Cin = x0.C + x1.C, c_clean = x0.C + pl.dirty, H = x0.H, W = x0.W;
   GemmArgs b;
   memset(&b, 0, sizeof b);
+  b.nz = e->cfg.nominal_batch;
   b.Hin = H; b.Win = W; b.Hout = H; b.Wout = W; b.Cout = Cout;
   b.ks = 3; b.stride = 1; b.pad = 1; b.silu = 1; b.ld_ps = Cin;
   b.w = P(c, wname); b.ldb = Cout;
@@ -923,7 +925,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   s.Cin = pl.nclean;
   s.pscale = sc + c_clean; s.pshift = sh + c_clean;
   s.wpk = reinterpret_cast<const char*>(it->second.p) + (size_t)(c_clean / 16) * 9 * 4 * it->second.cout_pad * 16;
-  if (splitk_factor(g) > 1 || splitk_factor(s) > 1) return 0;
+  if (splitk_factor_shared(g) > 1 || splitk_factor_shared(s) > 1) return 0;
   Act part;
   auto f = c.skip_part.find(p);
   const bool second = (f != c.skip_part.end());
@@ -1081,6 +1083,7 @@ int qkv_planes_conv(Ctx& c, const Act& x, const std::string& wname, const std::s
   pl->ld16 = 3 * C;
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.nz = e->cfg.nominal_batch;
   g.a0 = x.p; g.c0 = C; g.lda0 = C; g.a0_zo = x.per_image();
   g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.Cin = C; g.Cout = 3 * C; g.ks = 1; g.stride = 1;
   g.pscale = sc; g.pshift = sh; g.silu = 0;
@@ -1891,6 +1894,7 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   if (cfg->n_levels < 1 || cfg->n_levels > ASYRP_MAX_LEVELS || cfg->ch % 32 != 0 || max_batch < 1 || cfg->n_delta < 0 ||
       cfg->n_delta > 4 || cfg->resolution % (1 << (cfg->n_levels - 1)) != 0)
     return fail(ASYRP_EINVAL, "unsupported configuration");
+  if (cfg->nominal_batch < 0 || cfg->nominal_batch > 4096) return fail(ASYRP_EINVAL, "nominal_batch outside [0, 4096] (0 = the default class, 32)");
   // no device call here: the engine can be created (and its parameter inventory listed) without a GPU;
   // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
   asyrp_engine* e = new asyrp_engine();
