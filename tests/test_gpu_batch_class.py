@@ -58,3 +58,26 @@ def test_small_class_small_unet_vs_reference_fixture():
     assert_close(em, g["fwd_dual.et_mod"], what="small class et_mod")
     assert_close(dh, g["fwd_dual.delta_h"], what="small class delta_h")
     assert_close(mh, g["fwd_dual.middle_h"], what="small class middle_h")
+
+
+def test_small_class_iddpm_afhq_full_size_vs_reference_fixture():
+    """The iDDPM / ADM family on a small-class engine: i_DDPM('AFHQ') 256x256 (FiLM ResBlocks, up / down ResBlocks, 64-channel
+    heads), dual and single forward against the reference's own UNetModel outputs (the recipe of test_afhq_full_size_forward)."""
+    from asyrp_official_amd import i_DDPM
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    from oracle.weights import synthetic_state_dict
+    ga = load_golden("iddpm_afhq.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    m = i_DDPM("AFHQ", max_batch=1, nominal_batch=1)
+    m.setattr_layers(1)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = hash_normal("afhq.x", (1, 3, 256, 256), seed=4321)
+    t = torch.ones(1) * 768.0
+    et, em, dh, mh = m(x.cuda(), t.cuda(), index=0, t_edit=444, hs_coeff=(1.0, 1.0))
+    for name, got in (("fwd_dual.et", et), ("fwd_dual.et_mod", em), ("fwd_dual.delta_h", dh)):
+        print(name, err_stats(got, ga[name]))
+        assert_close(got, ga[name], what=f"small class AFHQ {name}")
+    et1, _, _, mh1 = m(x.cuda(), t.cuda())
+    assert_close(et1, ga["fwd_single.et"], what="small class AFHQ single et")
+    assert_close(mh1, ga["fwd_single.middle_h"], what="small class AFHQ single middle_h")
