@@ -684,6 +684,11 @@ static void try_gemm1x1(Ctx& c, const std::string& wname, GemmArgs& g) {
   g.cout_pad = it->second.cout_pad;
   g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
 }
+// A/B switch of the dedicated first-convolution kernel (ASYRP_CONV_IN=0: the implicit-GEMM tile with scalar-gather staging)
+static bool conv_in_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_IN"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
@@ -715,6 +720,20 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
   g.ZI = 1; g.Z = c.B;
   g.math = MATH_F32;
+  // the UNet's first convolution (3 input channels): an HBM-write-bound fp32 stencil (conv_in.hip) instead of a K = 32 tile of zeros
+  if (c.e->math == MATH_F16X3 && x0.C == 3 && !x1 && !sc0 && !ldb_full && conv_in_enabled() && conv_in_supported(g)) {
+    if (want_stats) {
+      out->st_nblk = conv_in_stat_blocks(g);
+      float* sp = nullptr;
+      TRY(c.e->pool.get((size_t)c.B * out->st_nblk * Cout * 4, &sp));
+      out->st = reinterpret_cast<double*>(sp);
+      g.stats = out->st;
+    }
+    double fl = 0, by = 0;
+    if (c.e->prof_on) gemm_work(g, &fl, &by);
+    if (fused) *fused = false;
+    return run_timed(c, 400000 + Cout, fl, by, [&]() { return launch_conv_in(g, c.s); });
+  }
   if (sc0 && c.e->math != MATH_F16X3) {   // fused shortcut exists only in the f16x3 family
     if (fused) *fused = false;
     drop(c, *out);
@@ -2751,6 +2770,20 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
       HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
       g.wpk = xg;
     }
+    if (tile == 17) {   // the first-convolution stencil (conv_in.hip): fp32 weights [tap][Cin][Cout] = `wp`
+      g.tile = 0; g.alpha = 1.f;
+      if (!conv_in_supported(g)) {
+        for (void* p : tmp) (void)hipFree(p);
+        return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel (3 input channels, 3x3, no prologue / residual / channel vector)");
+      }
+      hipError_t le = launch_conv_in(g, s);
+      if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);
+      hipError_t se = hipStreamSynchronize(s);
+      for (void* p : tmp) (void)hipFree(p);
+      if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_in launch: ") + hipGetErrorString(le));
+      if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_in sync: ") + hipGetErrorString(se));
+      return 0;
+    }
     if (tile == 13) {   // the taps-in-N kernel of the UNet's last conv (conv_out.hip): its own weight image
       std::vector<float> w1((size_t)9 * Cout * Cin);
       for (int co = 0; co < Cout; ++co)
@@ -2838,10 +2871,21 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
     HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
     g.wpk = xg;
   }
-  const int nblk = gemm_mblocks(g);
+  const bool cin_kernel = (tile == 17);   // conv_in.hip: fp32 weights [tap][Cin][Cout], its own statistics rows
+  if (cin_kernel) {
+    float* wp;
+    TRY(dalloc((size_t)ksize * ksize * Cin * Cout, &wp));
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(256), dim3(256), 0, s, weight, wp, Cout, Cin, ksize * ksize);
+    g.w = wp; g.ldb = Cout; g.tile = 0; g.alpha = 1.f;
+    if (!conv_in_supported(g)) {
+      for (void* p : tmp) (void)hipFree(p);
+      return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel");
+    }
+  }
+  const int nblk = cin_kernel ? conv_in_stat_blocks(g) : gemm_mblocks(g);
   TRY(dalloc((size_t)B * nblk * Cout * 4, &st));
   g.stats = reinterpret_cast<double*>(st);
-  hipError_t le = launch_gemm(g, s);
+  hipError_t le = cin_kernel ? launch_conv_in(g, s) : launch_gemm(g, s);
   GnFin2Args f;
   memset(&f, 0, sizeof f);
   f.p0 = g.stats; f.nblk0 = nblk; f.C0 = Cout; f.N = B; f.HW = HW; f.gamma = gamma; f.beta = beta; f.eps = eps;

@@ -104,6 +104,12 @@ void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 bool conv_out_supported(const GemmArgs& a);
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s);
 
+// conv_in.hip: the UNet's first convolution (3 -> Cout, 3x3, pad 1, no prologue) as an fp32 stencil; a.w = [tap][3][Cout] fp32,
+// statistics rows = 16 x 16 patches per image
+bool conv_in_supported(const GemmArgs& a);
+int conv_in_stat_blocks(const GemmArgs& a);
+hipError_t launch_conv_in(const GemmArgs& a, hipStream_t s);
+
 // GroupNorm(32) statistics of an NHWC tensor (two concatenated sources allowed) -> per-(image,channel)
 // scale/shift so that y = x*scale + shift == GN(x)*gamma+beta; optional FiLM (scale,shift) folding:
 // y = GN(x)*(1+fs)+fsh.  `partial` is scratch of gn_partial_floats() floats (holds doubles).

@@ -576,3 +576,48 @@ def test_splitk_16x16_layers(B, C0, C1, Cout, pro, res, math):
     else:
         err = float((got - want).abs().max())
         assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,Cout,H,W", [(2, 128, 32, 32), (1, 256, 40, 24), (3, 64, 16, 16), (1, 128, 256, 256)])
+def test_first_convolution_stencil_kernel(B, Cout, H, W):
+    """conv_in.hip (round 4): the 3 -> Cout first convolution as an fp32 stencil -- plain fp32 products like the reference's own,
+    ragged patches, 128 / 256 / 64 output channels, the full 256 x 256 size; image alone == image in batch bit for bit."""
+    x = hash_normal(f"cin.x.{B}.{H}", (B, 3, H, W))
+    w = hash_uniform(f"cin.w.{Cout}", (Cout, 3, 3, 3), -1, 1) / 27 ** 0.5
+    b = 0.1 * hash_uniform(f"cin.b.{Cout}", (Cout,))
+    got = hip_conv(x, w, b, tile=17)
+    assert_close(got, ref_conv(x, w, b), what="conv_in stencil", rtol=1e-5, atol=2e-6)
+    if B > 1:
+        alone = hip_conv(x[B - 1:B], w, b, tile=17)
+        assert torch.equal(alone[0], got[B - 1]), "conv_in stencil: result depends on the batch"
+
+
+def test_first_convolution_stencil_kernel_refuses_other_shapes():
+    from asyrp_official_amd import _lib
+    x, w, b = _mk(1, 32, 64, 16, 3, "cin.bad")           # 32 input channels
+    with pytest.raises(_lib.AsyrpError):
+        hip_conv(x, w, b, tile=17)
+
+
+@pytest.mark.parametrize("H,W,Cout,offset", [(32, 32, 128, 0.0), (40, 24, 128, 30.0), (16, 16, 256, 5.0)])
+def test_first_convolution_stencil_kernel_statistics(H, W, Cout, offset):
+    """GroupNorm partials of the stencil kernel's epilogue (norm1 of the first block) incl. ragged patches and a large mean."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    B, Cin = 2, 3
+    x = hash_normal(f"cinst.x.{H}", (B, Cin, H, W))
+    w = hash_uniform(f"cinst.w.{Cout}", (Cout, Cin, 3, 3), -1, 1) / 27 ** 0.5
+    b = 0.1 * hash_uniform(f"cinst.b.{Cout}", (Cout,)) + offset
+    gam, bet = 1 + 0.1 * hash_uniform("cinst.g", (Cout,)), 0.1 * hash_uniform("cinst.be", (Cout,))
+    d = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = map(d, (x, w, b, gam, bet))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    sc, sh = torch.empty((B, Cout), device="cuda"), torch.empty((B, Cout), device="cuda")
+    _lib.check(lib.asyrp_op_conv2d_stats(0, _p(xd), Cin, B, H, W, _p(wd), _p(bd), Cout, 3, 17, _p(gd), _p(bed), 1e-6,
+                                         _p(y), _p(sc), _p(sh), None))
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x, w, b, padding=1)
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-5, atol=2e-6 * max(1.0, offset))
+    got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
+    assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
