@@ -10,6 +10,8 @@
 // (rocprofv3, same box).  The 6-channel iDDPM head needs two N tiles and measured equal to the tile path, which it keeps.
 // One workgroup = an 8 x 16 output patch of one image (10 x 18 halo pixels = 6 MFMA row tiles), 4 waves; the whole weight image
 // (<= 32 KB) sits in LDS for the launch; Z goes through LDS (aliasing the staging buffers) for the stencil.
+// A 16 x 16 patch (halo overhead 1.27x instead of 1.41x) measured slower, 41 vs 45 TFLOP/s inside the edit: 58 KB of LDS leaves two
+// workgroups per CU instead of four (gpurun_out/r4prep_e, round-4 prep).
 #include <type_traits>
 #include "kernels.h"
 
