@@ -1680,14 +1680,17 @@ int splitk_factor_shared(const GemmArgs& a) { return splitk_factor_impl(a, false
 bool splitk_unfused(const GemmArgs& a) { return splitk_quad(a) || (small_class_tile(a) && small_class_sk(a) > 1); }
 bool splitk16(const GemmArgs& a) {
   static const bool on = [] { const char* e = getenv("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
-  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.rups && a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16 &&
+  // ASYRP_SPLITK32=1 (experiment, off by default): the same for the 32 x 32 maps on the 256-pixel form (4 x Cout/128 workgroups per image)
+  static const bool on32 = [] { const char* e = getenv("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
+  const bool m16 = a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16, m32 = on32 && a.Hout == 32 && a.Wout == 32 && a.Hin == 32 && a.Win == 32;
+  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.poly && !a.s0 && !a.rups && (m16 || m32) &&
          a.Cin >= 256 && (a.Cin % 64) == 0 && is_vec(a) && k32_preferred();
 }
 // the tile a split launch runs on (a function of the layer shape only, like the factor)
 int splitk_tile(const GemmArgs& a) {
   if (const int t = small_class_tile(a)) return t;
   if (splitk_quad(a)) return XT_256x128K32Q;
-  if (splitk16(a)) return XT_128x128K32;
+  if (splitk16(a)) return a.Hout == 32 ? XT_256x128K32 : XT_128x128K32;
   return XT_64x64;
 }
 bool splitk_quad(const GemmArgs& a) {
