@@ -12,6 +12,7 @@
 // (<= 32 KB) sits in LDS for the launch; Z goes through LDS (aliasing the staging buffers) for the stencil.
 // A 16 x 16 patch (halo overhead 1.27x instead of 1.41x) measured slower, 41 vs 45 TFLOP/s inside the edit: 58 KB of LDS leaves two
 // workgroups per CU instead of four (gpurun_out/r4prep_e, round-4 prep).
+#include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
 
@@ -237,26 +238,32 @@ size_t conv_out_smem(int Cin, int TN) {
   return (w + a + ps > z) ? w + a + ps : z;
 }
 
+bool conv_out_two_tiles() {
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return e && e[0] == '1'; }();
+  return on;
+}
 bool conv_out_supported(const GemmArgs& a) {
   return a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats &&
-         a.Cout * 9 <= 32 /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile: 581 vs 587 us */ && (a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
+         a.Cout * 9 <= (conv_out_two_tiles() ? 64 : 32) /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile in round 2, 581 vs 587 us,
+                                                                 before the loads went two chunks ahead: ASYRP_CONV_OUT6=1 re-enables it for a new A/B */ && (a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
 }
 
-template <int NP>
+template <int NP, int TN = 1>
 static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
-  const size_t smem = conv_out_smem(a.Cin, 1);
+  const size_t smem = conv_out_smem(a.Cin, TN);
   dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<1, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((conv_out_kernel<1, NP>), grid, block, smem, s, a);
+  hipLaunchKernelGGL((conv_out_kernel<TN, NP>), grid, block, smem, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
   if (!conv_out_supported(a)) return hipErrorInvalidValue;
+  if (a.Cout * 9 > 32) return a.np == 1 ? launch_conv_out_np<1, 2>(a, s) : launch_conv_out_np<3, 2>(a, s);
   return a.np == 1 ? launch_conv_out_np<1>(a, s) : launch_conv_out_np<3>(a, s);
 }
 

@@ -2078,7 +2078,7 @@ int asyrp_finalize_params(asyrp_engine* e) {
           // convolutions applied to a nearest-x2 up-sampled tensor: the four phase-collapsed 2x2 images (polyphase form)
           if (e->math == MATH_F16X3 && k == 3 && cin % 32 == 0 && is_upsampled_conv(e, s.key)) TRY(pack_x3_up(e, s.key, v, cout, cin));
           // the UNet's last conv (conv_out / out.2): a second image with the 9 taps folded into N for conv_out.hip
-          if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= 32 &&
+          if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= (conv_out_two_tiles() ? 64 : 32) &&
               cin % 16 == 0 && cin <= 256) {
             std::vector<float> w1((size_t)9 * cout * cin);
             for (int co = 0; co < cout; ++co)

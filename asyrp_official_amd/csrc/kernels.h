@@ -101,6 +101,7 @@ void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 
 // conv_out.hip: the UNet's last 3x3 convolution (Cout = 3 / 6) with the taps folded into N; `a.wpk` = f16x3 image of the equivalent
 // 1x1 conv w1[tap*Cout + co][ci] (launch_pack_f16x3 with cout = 9*Cout, ks = 1), prologue scale/shift + SiLU mandatory
+bool conv_out_two_tiles();                     // ASYRP_CONV_OUT6=1: the 6-channel iDDPM head on two N tiles of conv_out.hip (experiment)
 bool conv_out_supported(const GemmArgs& a);
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s);
 

@@ -367,7 +367,7 @@ def main():
                                         if world > 1 and backend == "nccl" else None),
                        # A/B switches read by the library from the environment: a non-default kernel choice can never be
                        # benchmarked silently
-                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16", "ASYRP_CONV_IN")},
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16", "ASYRP_SPLITK32", "ASYRP_CONV_IN", "ASYRP_CONV_OUT6")},
                        "conv_math": a.conv_math, "nominal_batch": a.nominal_batch or 32},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
