@@ -41,8 +41,11 @@ class HipUNet(nn.Module):
     """Base of `DDPM` and `UNetModel`: owns reference-named parameters, creates/synchronises the HIP engine on demand.
     Subclasses provide `_make_cfg(n_delta)`, `_temb_freqs()` and `resolution`."""
 
-    def _init_params(self, max_batch, conv_math):
+    def _init_params(self, max_batch, conv_math, nominal_batch=0):
         self.max_batch = int(max_batch)
+        # batch class of the engine (include/asyrp.h asyrp_config.nominal_batch): 0 = kernels priced at 32 images per GPU (default),
+        # 1 / 2 = the small class for single-image serving.  Fixed per engine; results of two classes agree to fp32 rounding.
+        self.nominal_batch = int(nominal_batch)
         # "f16x3" (3 x f16 MFMA, fp32-equivalent, default), "f32" (fp32 MFMA), or the fast mode "f16" (ONE f16 MFMA per product:
         # not fp32-equivalent, reported separately with its own error; include/asyrp.h enum asyrp_conv_math)
         self.conv_math = conv_math
@@ -104,7 +107,7 @@ class HipUNet(nn.Module):
             raise AsyrpDeviceError(f"{type(self).__name__} runs only on an MI355X (device type 'cuda' under ROCm); "
                                    "there is no CPU/PyTorch fallback")
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        sig = (idx, self._n_delta, self.max_batch)
+        sig = (idx, self._n_delta, self.max_batch, self.nominal_batch)
         if self._engine is None or self._engine_sig != sig:
             self._drop_engine()
             self._engine = Engine(self._make_cfg(self._n_delta), self.max_batch, idx)

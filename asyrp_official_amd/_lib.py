@@ -23,7 +23,7 @@ class AsyrpConfig(C.Structure):
                 ("out_channels", C.c_int32), ("ch", C.c_int32), ("n_levels", C.c_int32),
                 ("ch_mult", C.c_int32 * MAX_LEVELS), ("num_res_blocks", C.c_int32), ("n_attn", C.c_int32),
                 ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("num_head_channels", C.c_int32),
-                ("n_delta", C.c_int32), ("conv_math", C.c_int32), ("num_classes", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("n_delta", C.c_int32), ("conv_math", C.c_int32), ("num_classes", C.c_int32), ("nominal_batch", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int

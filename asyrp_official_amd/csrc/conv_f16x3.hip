@@ -901,7 +901,11 @@ struct K32Cfg {
 // NP:  matrix products per term.  3 = the fp32-equivalent two-term split (x_lo*w_hi + x_hi*w_hi + x_hi*w_lo); 1 = the single-
 //      product f16 mode (conv_math "f16": x_hi*w_hi only, fp32 accumulate): the lo planes are neither computed, staged,
 //      DMA'd nor read -- one third of the matrix work, half the weight bytes, a lighter staging pass.
-template <class T, bool SC, bool ABL = false, int NP = 3>
+// SPK: split-K on the plain forms (round 4): gridDim.y = N blocks * p.sk, every workgroup runs the chunks [cb, ce) of its range and
+//      writes alpha * acc to p.part[range][image][pixel][Cout]; launch_splitk_reduce adds the ranges in a fixed order with bias /
+//      timestep vector / residual and emits the GroupNorm partials.  For layers whose M x N offers fewer workgroups than the chip
+//      has slots (16 x 16 maps at B = 32: 256 workgroups of the 128-pixel form, one per CU).  No fused shortcut, no polyphase.
+template <class T, bool SC, bool ABL = false, int NP = 3, bool SPK = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE, WN = T::WN, WM = T::WM, TN = T::TN, BM = T::BM;
@@ -921,11 +925,13 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   constexpr int NTAPS = T::NTAPS, KW = T::KS;
   static_assert(!(POLY && SC), "the polyphase form has no fused shortcut");
   static_assert(!(QUAD && (SC || ABL)), "the quad form has no fused shortcut");
+  static_assert(!(SPK && (SC || ABL || POLY || QUAD)), "split-K: plain 3x3 forms only");
+  constexpr bool SPLIT = QUAD || SPK;
   // quad form: blockIdx.z = group of four images (zo = its first image), blockIdx.y = N block * sk + K range
   const int zo = POLY ? (int)blockIdx.z >> 2 : (QUAD ? (int)blockIdx.z * 4 : (int)blockIdx.z);
   const int phy = POLY ? ((int)blockIdx.z >> 1) & 1 : 0, phx = POLY ? (int)blockIdx.z & 1 : 0;
-  const int sk = QUAD ? p.sk : 1, ks_id = QUAD ? (int)blockIdx.y % sk : 0;
-  const int n0 = (QUAD ? (int)blockIdx.y / sk : (int)blockIdx.y) * BN;
+  const int sk = SPLIT ? p.sk : 1, ks_id = SPLIT ? (int)blockIdx.y % sk : 0;
+  const int n0 = (SPLIT ? (int)blockIdx.y / sk : (int)blockIdx.y) * BN;
   int bx = blockIdx.x;
   if (p.xmap) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);   // XCD-aware block -> tile map (see igemm_f16x3_kernel)
   const int tiles_x = (p.Wout + PW - 1) / PW;
@@ -1067,8 +1073,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0.f;
 
-  // split-K (quad form): this workgroup's chunks [cb, ce), an even number of them (launcher), i.e. whole K = 32 steps
-  const int cb = QUAD ? ks_id * (nch / sk) : 0, ce = QUAD ? cb + nch / sk : nch;
+  // split-K (quad form, SPK): this workgroup's chunks [cb, ce), an even number of them (launcher), i.e. whole K = 32 steps
+  const int cb = SPLIT ? ks_id * (nch / sk) : 0, ce = SPLIT ? cb + nch / sk : nch;
   const int s_first = cb * NTAPS / 2;
   issue_slot(s_first, s_first & 1);
   gload_A(cb);
@@ -1237,6 +1243,26 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
     return;
   }
+  if (SPK) {
+    // raw partial sums of this K range: part[range][image][pixel][Cout] (the layout launch_splitk_reduce reads)
+    const int gq = lane >> 4, HWo = p.Hout * p.Wout;
+    float* __restrict__ part = p.part + ((size_t)ks_id * p.Z + zo) * HWo * Cout;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + wn * WCH + tn * 16 + r16;
+      if (n >= Cout) continue;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * gq + r;
+          const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
+          if (oy < p.Hout && ox < p.Wout) part[(size_t)(oy * p.Wout + ox) * Cout + n] = acc[tm][tn][r] * p.alpha;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r ----
   float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
   const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
@@ -1355,10 +1381,10 @@ using K32Img8 = K32Cfg<8, 8, 8>;
 using K32S2 = K32Cfg<8, 8, 16, 2>;
 using K32Up = K32Cfg<8, 2, 16, 1, 2>;
 using K32Quad = K32Cfg<8, 2, 16, 1, 3, true>;
-template <class T, bool SC, bool ABL = false, int NP = 3>
+template <class T, bool SC, bool ABL = false, int NP = 3, bool SPK = false>
 static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   const int gx = T::QUAD ? 1 : ((a.Hout + T::PH - 1) / T::PH) * ((a.Wout + T::PW - 1) / T::PW);
-  const int gy = ((a.Cout + T::BN - 1) / T::BN) * (T::QUAD ? a.sk : 1);
+  const int gy = ((a.Cout + T::BN - 1) / T::BN) * ((T::QUAD || SPK) ? a.sk : 1);
   // polyphase form: one z-slice per (image, output phase); quad form: one per group of four images, K ranges along y
   dim3 grid(gx, gy, T::QUAD ? (a.Z + 3) / 4 : a.Z * (T::KS == 2 ? 4 : 1)), block(T::NT);
   GemmArgs ax = a;
@@ -1367,12 +1393,12 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (T::SMEM > 64 * 1024 && (dev < 0 || dev >= 16 || !attr_set[dev])) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<T, SC, ABL, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f16x3_k32_kernel<T, SC, ABL, NP, SPK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SMEM);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<T, SC, ABL, NP>), grid, block, T::SMEM, s, ax);
+  hipLaunchKernelGGL((igemm_f16x3_k32_kernel<T, SC, ABL, NP, SPK>), grid, block, T::SMEM, s, ax);
   return hipGetLastError();
 }
 
@@ -1383,6 +1409,12 @@ static bool k32_ok(const GemmArgs& a) {
 }
 static bool k32s2_ok(const GemmArgs& a) {
   return a.ks == 3 && a.stride == 2 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
+}
+// split-K on the plain K32 forms (GemmArgs.sk, .part, .tile = the form): whole K = 32 steps per range
+static bool k32spk_ok(const GemmArgs& a) {
+  if (!(a.tile == XT_256x128K32 || a.tile == XT_128x128K32 || a.tile == XT_64x128K32)) return false;
+  if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && !a.poly && !a.rups && a.sk >= 2 && a.part)) return false;
+  return (a.Cin & 31) == 0 && ((a.Cin / XKC) % (2 * a.sk)) == 0 && is_vec(a);
 }
 // A/B switch: ASYRP_MAIN_TILE=6 keeps the 32x32x16 organisation for the automatic choice
 static bool k32_preferred() {
@@ -1403,7 +1435,36 @@ int gemm_main_tile() { return XT_256x128W8; }
 // pre-summed biases vs two launches) and how the GroupNorm partial sums are partitioned (gemm_mblocks), so a
 // batch-dependent choice would make an image's bits depend on what it is batched or sharded with.
 constexpr int NOMINAL_Z = 32;   // BASELINE.json configs[1]: 32 images per GPU
+// Batch class (round 4).  The nominal batch is a property of the ENGINE (asyrp_config.nominal_batch, fixed at
+// asyrp_create; GemmArgs.nz; 0 = 32), never of the call, so an image's bits still do not depend on what it is batched with on that
+// engine.  The small class (nominal batch 1 or 2: single-image serving, the reference's bs_train = 1) keeps every 3x3 stride-1
+// layer with Cin % 32 == 0 on the K32 family -- 256-pixel form from 64 x 64 up, 128-pixel form at 32 x 32 and 16 x 16, the 8 x 8
+// patch form below -- and splits K until the launch offers >= 256 workgroups at the nominal batch (<= 8 ranges, whole K = 32
+// steps per range); no quad grouping.  Results across classes agree to fp32 rounding, like any two tile shapes.
+static int nominal_z(const GemmArgs& a) { return a.nz > 0 ? a.nz : NOMINAL_Z; }
+static bool is_vec(const GemmArgs& a);
+static bool k32_preferred();
+int small_class_tile(const GemmArgs& a) {   // 0: the default rules apply
+  if (nominal_z(a) > 2 || a.math != MATH_F16X3 || a.ks != 3 || a.stride != 1 || a.ups || a.abl || a.poly || a.rups) return 0;
+  if ((a.Cin & 31) || a.Cin < 32 || !is_vec(a) || !k32_preferred()) return 0;
+  const long long M = (long long)a.Hout * a.Wout;
+  if (M >= 4096) return XT_256x128K32;
+  if (M >= 256) return XT_128x128K32;
+  return (a.Hout == 8 && a.Wout == 8) ? XT_64x128K32 : 0;
+}
+int small_class_sk(const GemmArgs& a) {     // K ranges of a small-class launch of `a` WITHOUT a fused shortcut
+  const int t = small_class_tile(a);
+  if (!t) return 1;
+  const int bm = t == XT_256x128K32 ? 256 : (t == XT_128x128K32 ? 128 : 64), pw = bm >= 128 ? 16 : 8, ph = bm / pw;
+  const long long wgs = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw) * ((a.Cout + 127) / 128) * nominal_z(a);
+  int sk = 1;
+  while (sk < 8 && wgs * sk < 256) sk *= 2;
+  const int nch = a.Cin / XKC;
+  while (sk > 1 && (nch % (2 * sk)) != 0) sk /= 2;
+  return sk;
+}
 static int auto_tile_x(const GemmArgs& a) {
+  if (const int t = small_class_tile(a)) return t;
   if (a.stride == 2) return XT_64x128;
   const long long M = (long long)a.Hout * a.Wout;
   auto blocks = [&](int bm, int bn) {
@@ -1414,7 +1475,7 @@ static int auto_tile_x(const GemmArgs& a) {
       const int pw = bm >= 128 ? 16 : 8, ph = bm / pw;
       mt = (long long)((a.Hout + ph - 1) / ph) * ((a.Wout + pw - 1) / pw);
     }
-    return mt * ((a.Cout + bn - 1) / bn) * NOMINAL_Z;
+    return mt * ((a.Cout + bn - 1) / bn) * nominal_z(a);
   };
   if (a.Cout <= 32 && a.ks == 3 && M >= 256 && blocks(256, 32) >= 256) return XT_256x32;
   if (a.Cout <= 64) return (M >= 256 && blocks(256, 64) >= 256) ? XT_256x64 : XT_64x64;
@@ -1458,6 +1519,7 @@ static int eff_tile_x(const GemmArgs& a) {
   if (a.tile == XT_G1_256 || a.tile == XT_G1_128) return a.tile;   // set by the engine only after gemm1x1_ok()
   if (a.poly) return XT_256x128K32UP;
   if (a.tile == XT_256x128K32Q) return k32quad_ok(a) ? XT_256x128K32Q : XT_64x64;
+  if (a.sk > 1 && k32spk_ok(a)) return a.tile;                       // split-K on a plain K32 form (chosen by splitk_tile)
   if (a.stride == 2) return (k32s2_ok(a) && k32_preferred() && a.tile != XT_64x128) ? XT_64x128K32S2 : XT_64x128;
   int t = requested_tile_x(a);
   if (t == XT_256x128K32 && !k32_ok(a)) t = XT_256x128W8;
@@ -1530,6 +1592,11 @@ static hipError_t launch_gemm_f16x3_np(const GemmArgs& a, hipStream_t s) {
   }
   if (a.poly) return k32up_ok(a) ? launch_k32<K32Up, false, false, NP>(a, s) : hipErrorInvalidValue;
   if (tile == XT_256x128K32Q) return launch_k32<K32Quad, false, false, NP>(a, s);
+  if (a.sk > 1 && k32spk_ok(a)) {
+    if (tile == XT_256x128K32) return launch_k32<K32Main, false, false, NP, true>(a, s);
+    if (tile == XT_128x128K32) return launch_k32<K32Half, false, false, NP, true>(a, s);
+    return launch_k32<K32Img8, false, false, NP, true>(a, s);
+  }
   if (a.abl && NP != 3) return hipErrorInvalidValue;
   if (a.abl) {   // timing ablations of the main tile: instantiated in the profiling library only (libasyrp_hip_bench.so)
 #ifdef ASYRP_BENCH_HOOKS
@@ -1590,19 +1657,45 @@ constexpr int SKR_PIX = 8;    // pixels per reduce workgroup == pixels per stati
 
 int splitk_stat_blocks(int HW) { return (HW + SKR_PIX - 1) / SKR_PIX; }
 
-int splitk_factor(const GemmArgs& a) {
+static int splitk_factor_impl(const GemmArgs& a, bool allow16) {
   if (a.math != MATH_F16X3 || !a.wpk || a.ks != 3 || a.stride != 1 || a.ups || a.s0 || a.rups || a.abl) return 1;
   // measured (profiles/r01_conv_microbench_kb8_splitk.txt, B=32): 1024->512 @8x8 179 -> 134 us; 512->512 @8x8 no gain (91 us
   // either way: with 32 chunks a workgroup's fixed prologue/epilogue latency equals its share of the loop)
   // round 3: with the quad form (four images per workgroup, K32Cfg<8, 2, 16, 1, 3, true>) every 8 x 8 layer with Cin % 256 == 0
   // splits, 512 -> 512 included; the 64 x 64 tile keeps the old rule (Cin >= 1024)
+  // round 4: the 16 x 16 maps on the 128-pixel K32 form offer 2 x Cout/128 workgroups per image -- 256 at the nominal batch, one
+  // per CU with two waves per SIMD (matrix pipe 32 % busy, half of the wave cycles parked: profiles/rd3_pmc_families_*) -- a 2-way K
+  // split fills the second slot (ASYRP_SPLITK16=0: off).  Blocks with a fused 1x1 shortcut keep the single-pass form (a.s0 above).
+  if (small_class_tile(a)) return small_class_sk(a);
+  if (allow16 && splitk16(a)) return 2;
   if (a.Hout * a.Wout > 64 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
   if (splitk_quad(a)) return 8;
   return a.Cin >= 1024 ? 8 : 1;
 }
+int splitk_factor(const GemmArgs& a) { return splitk_factor_impl(a, true); }
+// for the partial launches of a dual step's shared skip half (engine.hip conv1_shared): sharing is worth more than the 16 x 16 split
+int splitk_factor_shared(const GemmArgs& a) { return splitk_factor_impl(a, false); }
+// a block's 1x1 shortcut runs as its own launch (and enters the reduce as the residual) instead of being fused: the quad form, and
+// the small class whenever the unfused conv splits K
+bool splitk_unfused(const GemmArgs& a) { return splitk_quad(a) || (small_class_tile(a) && small_class_sk(a) > 1); }
+bool splitk16(const GemmArgs& a) {
+  static const bool on = [] { const char* e = getenv("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
+  // ASYRP_SPLITK32=1 (experiment, off by default): the same for the 32 x 32 maps on the 256-pixel form (4 x Cout/128 workgroups per image)
+  static const bool on32 = [] { const char* e = getenv("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
+  const bool m16 = a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16, m32 = on32 && a.Hout == 32 && a.Wout == 32 && a.Hin == 32 && a.Win == 32;
+  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.poly && !a.s0 && !a.rups && (m16 || m32) &&
+         a.Cin >= 256 && (a.Cin % 64) == 0 && is_vec(a) && k32_preferred();
+}
+// the tile a split launch runs on (a function of the layer shape only, like the factor)
+int splitk_tile(const GemmArgs& a) {
+  if (const int t = small_class_tile(a)) return t;
+  if (splitk_quad(a)) return XT_256x128K32Q;
+  if (splitk16(a)) return a.Hout == 32 ? XT_256x128K32 : XT_128x128K32;
+  return XT_64x64;
+}
 bool splitk_quad(const GemmArgs& a) {
   static const bool on = [] { const char* e = getenv("ASYRP_QUAD8"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
-  return on && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
+  return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
          (a.Cin % 256) == 0 && a.a0_zo == 64LL * a.lda0 && (!a.a1 || a.a1_zo == 64LL * a.lda1);
 }
 
@@ -1660,6 +1753,8 @@ hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
   const int HW = a.Hout * a.Wout;
   const dim3 grid(splitk_stat_blocks(HW), a.Z);
   if (a.sk == 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(256), 0, s, a, HW);
+  else if (a.sk == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(256), 0, s, a, HW);
+  else if (a.sk == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, a, HW);
   else hipLaunchKernelGGL(splitk_reduce_kernel<0>, grid, dim3(256), 0, s, a, HW);
   return hipGetLastError();
 }

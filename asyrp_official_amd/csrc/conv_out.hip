@@ -10,6 +10,10 @@
 // (rocprofv3, same box).  The 6-channel iDDPM head needs two N tiles and measured equal to the tile path, which it keeps.
 // One workgroup = an 8 x 16 output patch of one image (10 x 18 halo pixels = 6 MFMA row tiles), 4 waves; the whole weight image
 // (<= 32 KB) sits in LDS for the launch; Z goes through LDS (aliasing the staging buffers) for the stencil.
+// A 16 x 16 patch (halo overhead 1.27x instead of 1.41x) measured slower, 41 vs 45 TFLOP/s inside the edit: 58 KB of LDS leaves two
+// workgroups per CU instead of four (gpurun_out/r4prep_e, round-4 prep).
+#include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 namespace asyrp {
@@ -58,6 +62,8 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   char* const Ws = smem;                                // [chunk][4][BN][16 B]
   char* const As = smem + W_BYTES;                      // 2 x A_BYTES
   float* const Zs = reinterpret_cast<float*>(smem);     // after the K loop: [CO_MT*32][ZLD] floats (aliases Ws / As)
+  float* const Ps = reinterpret_cast<float*>(smem + W_BYTES + 2 * A_BYTES);   // scale[Cin] | shift[Cin] of this image (a global load
+                                                        // inside the staging pass would sit behind the prefetched chunk in vmcnt order)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +75,10 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   const float* __restrict__ ps = p.pscale + (long long)zo * p.Cin;
   const float* __restrict__ psh = p.pshift + (long long)zo * p.Cin;
 
+  for (int i = tid; i < p.Cin; i += NT) {
+    Ps[i] = ps[i];
+    Ps[p.Cin + i] = psh[i];
+  }
   // ---- weights -> LDS (once) ----
   {
     const char* wpk = reinterpret_cast<const char*>(p.wpk);
@@ -92,34 +102,39 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
     }
     aoff[i] = off;
   }
-  float4 areg[NA][2];
-  auto gload = [&](int chunk) {
+  // Two register sets: the loads of chunk c + 2 are issued while chunk c + 1 is staged and chunk c multiplied, so two chunks of the
+  // tile are in flight per workgroup (round 3's counters: 62 % of this kernel's wave cycles were parked behind one chunk's loads).
+  // Loads are unconditional (padding pixels and surplus work items read pixel 0 and are zeroed at staging time) and the set
+  // index is a compile-time constant: hipcc then counts them and waits with vmcnt(2 * NA) for the older set only.
+  float4 areg[2][NA][2];
+  auto gload = [&](int chunk, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const float* base = a0 + chunk * 16 + hf * 8;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (aoff[i] >= 0) {
-        const float* src = base + (long long)aoff[i] * p.lda0;
-        v0 = *reinterpret_cast<const float4*>(src);
-        v1 = *reinterpret_cast<const float4*>(src + 4);
-      }
-      areg[i][0] = v0;
-      areg[i][1] = v1;
+      const float* src = base + (long long)max(aoff[i], 0) * p.lda0;
+      areg[set][i][0] = *reinterpret_cast<const float4*>(src);
+      areg[set][i][1] = *reinterpret_cast<const float4*>(src + 4);
     }
   };
-  auto stage = [&](int chunk, int buf) {
+  auto stage = [&](int chunk, int buf, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int c = chunk * 16 + hf * 8;
-    const float4 s0 = *reinterpret_cast<const float4*>(ps + c), s1 = *reinterpret_cast<const float4*>(ps + c + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(psh + c), h1 = *reinterpret_cast<const float4*>(psh + c + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(Ps + c), s1 = *reinterpret_cast<const float4*>(Ps + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(Ps + p.Cin + c), h1 = *reinterpret_cast<const float4*>(Ps + p.Cin + c + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (aoff[i] == -2) continue;
-      float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w, areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      float t[8] = {areg[set][i][0].x, areg[set][i][0].y, areg[set][i][0].z, areg[set][i][0].w,
+                    areg[set][i][1].x, areg[set][i][1].y, areg[set][i][1].z, areg[set][i][1].w};
       if (aoff[i] >= 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = co_silu(__builtin_fmaf(t[j], sc[j], sh[j]));
+      } else {   // zero padding of the 3x3 conv (the clamped load above fetched pixel 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = 0.f;
       }
       h8 hi, lo;
       co_split8(t, hi, lo);
@@ -144,12 +159,9 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
 
-  gload(0);
-  stage(0, 0);
-  __syncthreads();
-  for (int chunk = 0; chunk < nch; ++chunk) {
-    const bool more = chunk + 1 < nch;
-    if (more) gload(chunk + 1);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto mma_chunk = [&](int chunk) {
     const char* A = As + (chunk & 1) * A_BYTES + kh * CO_NPIX * 16;
     const char* B = Ws + ((size_t)chunk * 4 + kh) * BN * 16 + (lane & 31) * 16;
 #pragma unroll
@@ -170,7 +182,23 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
         }
       }
     }
-    if (more) stage(chunk + 1, (chunk + 1) & 1);
+  };
+  // chunk c lives in register set c & 1 until it is staged; loads past the last chunk re-read it (static load counts)
+  gload(0, S0{});
+  gload(min(1, nch - 1), S1{});
+  stage(0, 0, S0{});
+  __syncthreads();
+  for (int chunk = 0; chunk < nch; chunk += 2) {   // nch is even (launcher: Cin % 32 == 0)
+    // even chunk: set 0 is free (staged before the last barrier) -> chunk + 2; multiply chunk; stage chunk + 1 from set 1.
+    // Every iteration issues the same loads and the same staging pass (past the end: the last chunk again, into the buffer nobody
+    // reads any more), so the body is straight-line code with static counts.
+    gload(min(chunk + 2, nch - 1), S0{});
+    mma_chunk(chunk);
+    stage(chunk + 1, 1, S1{});
+    __syncthreads();
+    gload(min(chunk + 3, nch - 1), S1{});
+    mma_chunk(chunk + 1);
+    stage(min(chunk + 2, nch - 1), 0, S0{});
     __syncthreads();
   }
 
@@ -206,30 +234,36 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
 
 size_t conv_out_smem(int Cin, int TN) {
   const size_t w = (size_t)(Cin / 16) * 4 * 32 * TN * 16, a = 2 * (size_t)CO_NPIX * 64;
-  const size_t z = (size_t)CO_MT * 32 * (32 * TN + 1) * sizeof(float);
-  return (w + a > z) ? w + a : z;
+  const size_t z = (size_t)CO_MT * 32 * (32 * TN + 1) * sizeof(float), ps = 2 * (size_t)Cin * sizeof(float);
+  return (w + a + ps > z) ? w + a + ps : z;
 }
 
+bool conv_out_two_tiles() {
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return e && e[0] == '1'; }();
+  return on;
+}
 bool conv_out_supported(const GemmArgs& a) {
   return a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats &&
-         a.Cout * 9 <= 32 /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile: 581 vs 587 us */ && (a.Cin & 15) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
+         a.Cout * 9 <= (conv_out_two_tiles() ? 64 : 32) /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile in round 2, 581 vs 587 us,
+                                                                 before the loads went two chunks ahead: ASYRP_CONV_OUT6=1 re-enables it for a new A/B */ && (a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
 }
 
-template <int NP>
+template <int NP, int TN = 1>
 static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
-  const size_t smem = conv_out_smem(a.Cin, 1);
+  const size_t smem = conv_out_smem(a.Cin, TN);
   dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<1, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((conv_out_kernel<1, NP>), grid, block, smem, s, a);
+  hipLaunchKernelGGL((conv_out_kernel<TN, NP>), grid, block, smem, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
   if (!conv_out_supported(a)) return hipErrorInvalidValue;
+  if (a.Cout * 9 > 32) return a.np == 1 ? launch_conv_out_np<1, 2>(a, s) : launch_conv_out_np<3, 2>(a, s);
   return a.np == 1 ? launch_conv_out_np<1>(a, s) : launch_conv_out_np<3>(a, s);
 }
 

@@ -684,6 +684,11 @@ static void try_gemm1x1(Ctx& c, const std::string& wname, GemmArgs& g) {
   g.cout_pad = it->second.cout_pad;
   g.alpha = 1.0f / (it->second.wscale * f16x3_act_scale());
 }
+// A/B switch of the dedicated first-convolution kernel (ASYRP_CONV_IN=0: the implicit-GEMM tile with scalar-gather staging)
+static bool conv_in_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_IN"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
 int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const std::string& bname, int Cout, int ks,
          int stride, int ups, const float* pscale, const float* pshift, int silu, const float* chan_add,
@@ -696,6 +701,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   TRY(new_act(c, Cout, Ho, Wo, out));
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.nz = c.e->cfg.nominal_batch;
   g.a0 = x0.p; g.c0 = x0.C; g.lda0 = x0.C; g.a0_zo = x0.per_image();
   if (x1) { g.a1 = x1->p; g.c1 = x1->C; g.lda1 = x1->C; g.a1_zo = x1->per_image(); }
   g.Hin = Hin; g.Win = Win; g.Hout = Ho; g.Wout = Wo;
@@ -714,6 +720,20 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
   g.ZI = 1; g.Z = c.B;
   g.math = MATH_F32;
+  // the UNet's first convolution (3 input channels): an HBM-write-bound fp32 stencil (conv_in.hip) instead of a K = 32 tile of zeros
+  if (c.e->math == MATH_F16X3 && x0.C == 3 && !x1 && !sc0 && !ldb_full && conv_in_enabled() && conv_in_supported(g)) {
+    if (want_stats) {
+      out->st_nblk = conv_in_stat_blocks(g);
+      float* sp = nullptr;
+      TRY(c.e->pool.get((size_t)c.B * out->st_nblk * Cout * 4, &sp));
+      out->st = reinterpret_cast<double*>(sp);
+      g.stats = out->st;
+    }
+    double fl = 0, by = 0;
+    if (c.e->prof_on) gemm_work(g, &fl, &by);
+    if (fused) *fused = false;
+    return run_timed(c, 400000 + Cout, fl, by, [&]() { return launch_conv_in(g, c.s); });
+  }
   if (sc0 && c.e->math != MATH_F16X3) {   // fused shortcut exists only in the f16x3 family
     if (fused) *fused = false;
     drop(c, *out);
@@ -733,7 +753,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
       const float* fb = P(c, bname + "#sc");
       // 8 x 8 layers: the quad form (four images per workgroup, split-K) without the fusion beats the fused 64-pixel form --
       // 46 us + a 1x1 launch against 150 us -- so these blocks take the two-launch form (the shortcut enters the reduce as the residual)
-      if (fit != c.e->xw.end() && fb && !resid && !splitk_quad(g)) {
+      if (fit != c.e->xw.end() && fb && !resid && !splitk_unfused(g)) {
         GemmArgs t = g;
         t.s0 = sc0->p; t.sc0 = sc0->C; t.lds0 = sc0->C; t.s0_zo = sc0->per_image();
         if (sc1) { t.s1 = sc1->p; t.sc1 = sc1->C; t.lds1 = sc1->C; t.s1_zo = sc1->per_image(); }
@@ -788,7 +808,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     const int sk = splitk_factor(g);
     if (sk > 1) {
       g.sk = sk;
-      g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+      g.tile = splitk_tile(g);
       TRY(c.e->pool.get((size_t)sk * c.B * Ho * Wo * Cout, &g.part));
     }
     if (want_stats) {   // the output will be group-normalised: its statistics come out of this launch's epilogue
@@ -904,6 +924,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   const int Cin = x0.C + x1.C, c_clean = x0.C + pl.dirty, H = x0.H, W = x0.W;
   GemmArgs b;
   memset(&b, 0, sizeof b);
+  b.nz = e->cfg.nominal_batch;
   b.Hin = H; b.Win = W; b.Hout = H; b.Wout = W; b.Cout = Cout;
   b.ks = 3; b.stride = 1; b.pad = 1; b.silu = 1; b.ld_ps = Cin;
   b.w = P(c, wname); b.ldb = Cout;
@@ -923,7 +944,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   s.Cin = pl.nclean;
   s.pscale = sc + c_clean; s.pshift = sh + c_clean;
   s.wpk = reinterpret_cast<const char*>(it->second.p) + (size_t)(c_clean / 16) * 9 * 4 * it->second.cout_pad * 16;
-  if (splitk_factor(g) > 1 || splitk_factor(s) > 1) return 0;
+  if (splitk_factor_shared(g) > 1 || splitk_factor_shared(s) > 1) return 0;
   Act part;
   auto f = c.skip_part.find(p);
   const bool second = (f != c.skip_part.end());
@@ -1081,6 +1102,7 @@ int qkv_planes_conv(Ctx& c, const Act& x, const std::string& wname, const std::s
   pl->ld16 = 3 * C;
   GemmArgs g;
   memset(&g, 0, sizeof g);
+  g.nz = e->cfg.nominal_batch;
   g.a0 = x.p; g.c0 = C; g.lda0 = C; g.a0_zo = x.per_image();
   g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.Cin = C; g.Cout = 3 * C; g.ks = 1; g.stride = 1;
   g.pscale = sc; g.pshift = sh; g.silu = 0;
@@ -1891,6 +1913,7 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   if (cfg->n_levels < 1 || cfg->n_levels > ASYRP_MAX_LEVELS || cfg->ch % 32 != 0 || max_batch < 1 || cfg->n_delta < 0 ||
       cfg->n_delta > 4 || cfg->resolution % (1 << (cfg->n_levels - 1)) != 0)
     return fail(ASYRP_EINVAL, "unsupported configuration");
+  if (cfg->nominal_batch < 0 || cfg->nominal_batch > 4096) return fail(ASYRP_EINVAL, "nominal_batch outside [0, 4096] (0 = the default class, 32)");
   // no device call here: the engine can be created (and its parameter inventory listed) without a GPU;
   // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
   asyrp_engine* e = new asyrp_engine();
@@ -2055,7 +2078,7 @@ int asyrp_finalize_params(asyrp_engine* e) {
           // convolutions applied to a nearest-x2 up-sampled tensor: the four phase-collapsed 2x2 images (polyphase form)
           if (e->math == MATH_F16X3 && k == 3 && cin % 32 == 0 && is_upsampled_conv(e, s.key)) TRY(pack_x3_up(e, s.key, v, cout, cin));
           // the UNet's last conv (conv_out / out.2): a second image with the 9 taps folded into N for conv_out.hip
-          if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= 32 &&
+          if (e->math == MATH_F16X3 && k == 3 && (s.key == "conv_out.weight" || s.key == "out.2.weight") && cout * 9 <= (conv_out_two_tiles() ? 64 : 32) &&
               cin % 16 == 0 && cin <= 256) {
             std::vector<float> w1((size_t)9 * cout * cin);
             for (int co = 0; co < cout; ++co)
@@ -2747,6 +2770,20 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
       HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
       g.wpk = xg;
     }
+    if (tile == 17) {   // the first-convolution stencil (conv_in.hip): fp32 weights [tap][Cin][Cout] = `wp`
+      g.tile = 0; g.alpha = 1.f;
+      if (!conv_in_supported(g)) {
+        for (void* p : tmp) (void)hipFree(p);
+        return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel (3 input channels, 3x3, no prologue / residual / channel vector)");
+      }
+      hipError_t le = launch_conv_in(g, s);
+      if (le == hipSuccess) le = launch_nhwc_to_nchw(yo, Cout, y, B, Cout, Ho * Wo, s);
+      hipError_t se = hipStreamSynchronize(s);
+      for (void* p : tmp) (void)hipFree(p);
+      if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_in launch: ") + hipGetErrorString(le));
+      if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv_in sync: ") + hipGetErrorString(se));
+      return 0;
+    }
     if (tile == 13) {   // the taps-in-N kernel of the UNet's last conv (conv_out.hip): its own weight image
       std::vector<float> w1((size_t)9 * Cout * Cin);
       for (int co = 0; co < Cout; ++co)
@@ -2777,7 +2814,7 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
   const int sk = (tile == 0 && g.math == MATH_F16X3) ? splitk_factor(g) : 1;
   if (sk > 1) {
     g.sk = sk;
-    g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+    g.tile = splitk_tile(g);
     TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part));
   }
   hipError_t le = launch_gemm(g, s);
@@ -2834,10 +2871,21 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
     HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
     g.wpk = xg;
   }
-  const int nblk = gemm_mblocks(g);
+  const bool cin_kernel = (tile == 17);   // conv_in.hip: fp32 weights [tap][Cin][Cout], its own statistics rows
+  if (cin_kernel) {
+    float* wp;
+    TRY(dalloc((size_t)ksize * ksize * Cin * Cout, &wp));
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(256), dim3(256), 0, s, weight, wp, Cout, Cin, ksize * ksize);
+    g.w = wp; g.ldb = Cout; g.tile = 0; g.alpha = 1.f;
+    if (!conv_in_supported(g)) {
+      for (void* p : tmp) (void)hipFree(p);
+      return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel");
+    }
+  }
+  const int nblk = cin_kernel ? conv_in_stat_blocks(g) : gemm_mblocks(g);
   TRY(dalloc((size_t)B * nblk * Cout * 4, &st));
   g.stats = reinterpret_cast<double*>(st);
-  hipError_t le = launch_gemm(g, s);
+  hipError_t le = cin_kernel ? launch_conv_in(g, s) : launch_gemm(g, s);
   GnFin2Args f;
   memset(&f, 0, sizeof f);
   f.p0 = g.stats; f.nblk0 = nblk; f.C0 = Cout; f.N = B; f.HW = HW; f.gamma = gamma; f.beta = beta; f.eps = eps;
@@ -3004,7 +3052,7 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   const int sk = (tile == 0) ? splitk_factor(g) : 1;   // as the engine does when it picks the tile itself
   if (sk > 1) {
     g.sk = sk;
-    g.tile = splitk_quad(g) ? XT_256x128K32Q : XT_64x64;
+    g.tile = splitk_tile(g);
     TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part, 0.f, 11));
   }
   auto once = [&]() -> hipError_t {

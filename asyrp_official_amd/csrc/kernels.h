@@ -59,6 +59,7 @@ struct GemmArgs {
   // (n % v_mod - v_off) for the channels with n % v_mod >= v_off (DDPM q|k|v blocks: v_mod = 3C, v_off = 2C, v_dh = C; the legacy
   // per-head [q|k|v] order of improved_ddpm/unet.py:389: v_mod = 3 Dh, v_off = 2 Dh, v_dh = Dh)
   _Float16* o16h; _Float16* o16l; _Float16* vth; _Float16* vtl; int ld16, v_mod, v_off, v_dh; long long o16_zo, vt_zo;
+  int nz;                         // nominal batch of the engine's batch class (tile / split-K rules are priced at it, never at Z); 0 = 32
   int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
 };
 
@@ -100,8 +101,15 @@ void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 
 // conv_out.hip: the UNet's last 3x3 convolution (Cout = 3 / 6) with the taps folded into N; `a.wpk` = f16x3 image of the equivalent
 // 1x1 conv w1[tap*Cout + co][ci] (launch_pack_f16x3 with cout = 9*Cout, ks = 1), prologue scale/shift + SiLU mandatory
+bool conv_out_two_tiles();                     // ASYRP_CONV_OUT6=1: the 6-channel iDDPM head on two N tiles of conv_out.hip (experiment)
 bool conv_out_supported(const GemmArgs& a);
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s);
+
+// conv_in.hip: the UNet's first convolution (3 -> Cout, 3x3, pad 1, no prologue) as an fp32 stencil; a.w = [tap][3][Cout] fp32,
+// statistics rows = 16 x 16 patches per image
+bool conv_in_supported(const GemmArgs& a);
+int conv_in_stat_blocks(const GemmArgs& a);
+hipError_t launch_conv_in(const GemmArgs& a, hipStream_t s);
 
 // GroupNorm(32) statistics of an NHWC tensor (two concatenated sources allowed) -> per-(image,channel)
 // scale/shift so that y = x*scale + shift == GN(x)*gamma+beta; optional FiLM (scale,shift) folding:
@@ -122,8 +130,12 @@ int gn_nblk_of(int HW);                       // M-blocks launch_gn_partial writ
 // out = sum_ks part[ks] + bias + chan_add + resid; stats (nullable) = [Z][splitk_stat_blocks(HW)][Cout][2] doubles
 hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int splitk_stat_blocks(int HW);
+int splitk_factor_shared(const GemmArgs& a);   // the same without the 16 x 16 rule (partial launches of a shared skip half)
 int splitk_factor(const GemmArgs& a);   // 1 = none; a function of the LAYER SHAPE only (batch-invariant results)
 bool splitk_quad(const GemmArgs& a);    // the split launch runs on the quad form (XT_256x128K32Q) instead of the 64x64 tile
+bool splitk16(const GemmArgs& a);       // 16 x 16 maps: 2-way split on the 128-pixel K32 form (round 4)
+bool splitk_unfused(const GemmArgs& a);  // a block's 1x1 shortcut must run as its own launch (quad form, small batch class)
+int splitk_tile(const GemmArgs& a);     // XT_* a split launch of `a` runs on (quad form, a plain K32 form, or the 64x64 tile)
 int gemm_main_tile();
 bool gemm_can_fuse_shortcut(const GemmArgs& a);   // true when launch_gemm_f16x3 would run `a` (with s0/Cin2 set) on the fusing tile
 int gemm_mblocks(const GemmArgs& a);          // M-blocks (gridDim.x) launch_gemm_f16x3 will use -> rows of GemmArgs.stats

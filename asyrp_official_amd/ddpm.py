@@ -17,7 +17,7 @@ def _cfg_get(ns, name, default=None):
 
 
 class DDPM(HipUNet):
-    def __init__(self, config, max_batch=64, conv_math="f16x3"):
+    def __init__(self, config, max_batch=64, conv_math="f16x3", nominal_batch=0):
         super().__init__()
         self.config = config
         m, d = _cfg_get(config, "model"), _cfg_get(config, "data")
@@ -32,7 +32,7 @@ class DDPM(HipUNet):
             raise NotImplementedError("resamp_with_conv=False is not used by any reference config")
         self.temb_ch = self.ch * 4
         self.num_resolutions = len(self.ch_mult)
-        self._init_params(max_batch, conv_math)
+        self._init_params(max_batch, conv_math, nominal_batch)
 
     def get_temb(self, t):
         """models/ddpm/diffusion.py:464-470: dense1(swish(dense0(get_timestep_embedding(t, ch)))) -> [B, 4*ch]."""
@@ -46,7 +46,7 @@ class DDPM(HipUNet):
         return make_config(family=_lib.FAMILY_DDPM, resolution=self.resolution, in_channels=self.in_channels,
                            out_channels=self.out_ch, ch=self.ch, ch_mult=self.ch_mult,
                            num_res_blocks=self.num_res_blocks, attn_resolutions=self.attn_resolutions,
-                           n_delta=n_delta, conv_math=self.conv_math)
+                           n_delta=n_delta, conv_math=self.conv_math, nominal_batch=self.nominal_batch)
 
     def _temb_freqs(self):
         return ddpm_temb_freqs(self.ch)

@@ -9,7 +9,7 @@ from . import _lib
 
 
 def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channels, ch, ch_mult, num_res_blocks,
-                attn_resolutions, num_head_channels=0, n_delta=0, conv_math="f16x3", num_classes=0):
+                attn_resolutions, num_head_channels=0, n_delta=0, conv_math="f16x3", num_classes=0, nominal_batch=0):
     cfg = _lib.AsyrpConfig()
     cfg.family, cfg.resolution, cfg.in_channels, cfg.out_channels = family, resolution, in_channels, out_channels
     cfg.ch, cfg.n_levels, cfg.num_res_blocks = ch, len(ch_mult), num_res_blocks
@@ -21,6 +21,7 @@ def make_config(*, family=_lib.FAMILY_DDPM, resolution, in_channels, out_channel
     cfg.num_head_channels, cfg.n_delta = num_head_channels, n_delta
     cfg.conv_math = _lib.CONV_MATH[conv_math] if isinstance(conv_math, str) else int(conv_math)
     cfg.num_classes = int(num_classes)
+    cfg.nominal_batch = int(nominal_batch)      # batch class (include/asyrp.h): 0 = priced at 32 images, 1 / 2 = the small class
     return cfg
 
 
@@ -282,6 +283,8 @@ class Engine:
             return "attention", "asyrp::attn_f16x3_kernel (T=%d)" % (v - 200000)
         if fam == 3:
             return "f16x3", "asyrp::conv_out_kernel (Cout=%d)" % (v - 300000)
+        if fam == 4:
+            return "f16x3", "asyrp::conv_in_kernel (Cout=%d)" % (v - 400000)
         if fam == 1:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
                     12: (4, 1, 2, 1)}.get(tid, (0,) * 4)

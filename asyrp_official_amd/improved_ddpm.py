@@ -39,7 +39,7 @@ class UNetModel(HipUNet):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
                  use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
-                 resblock_updown=False, use_new_attention_order=False, max_batch=64, conv_math="f16x3"):
+                 resblock_updown=False, use_new_attention_order=False, max_batch=64, conv_math="f16x3", nominal_batch=0):
         super().__init__()
         unsupported = []
         if not resblock_updown: unsupported.append("resblock_updown=False")
@@ -59,7 +59,7 @@ class UNetModel(HipUNet):
         self.dropout, self.conv_resample, self.use_checkpoint = dropout, conv_resample, use_checkpoint
         self.dtype = torch.float32
         self.resolution = self.image_size
-        self._init_params(max_batch, conv_math)
+        self._init_params(max_batch, conv_math, nominal_batch)
 
     def forward(self, x, timesteps, y=None, index=None, t_edit=400, hs_coeff=(1.0, 1.0), delta_h=None,
                 ignore_timestep=False, use_mask=False):
@@ -72,7 +72,7 @@ class UNetModel(HipUNet):
                            num_res_blocks=self.num_res_blocks,
                            attn_resolutions=tuple(self.image_size // ds for ds in self.attention_resolutions),
                            num_head_channels=self.num_head_channels, n_delta=n_delta, conv_math=self.conv_math,
-                           num_classes=int(self.num_classes or 0))
+                           num_classes=int(self.num_classes or 0), nominal_batch=self.nominal_batch)
 
     def _temb_freqs(self):
         return iddpm_temb_freqs(self.model_channels)

@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--nominal-batch", type=int, default=0,
+                    help="batch class of the engine (asyrp_config.nominal_batch): 0 = kernels priced at 32 images per GPU (default, the "
+                         "line of record), 1 = the small class for single-image serving (use with --batch 1)")
     ap.add_argument("--conv-math", choices=["f16x3", "f32", "f16"], default="f16x3",
                     help="f16x3: 3 x f16 MFMA per product, fp32-equivalent (default, the line of record); f32: fp32-input MFMA; "
                          "f16: the FAST mode - one f16 MFMA per product, not fp32-equivalent, reported as a separate line whose "
@@ -254,9 +257,9 @@ def main():
     B = a.batch or {"celeba": 32, "church": 32, "afhq": 64, "imagenet": 16}[a.config]
     torch.manual_seed(1234)                     # main.py:301 default seed
     if family == "ddpm":
-        model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math)   # configs/church.yml has the same model block
+        model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math, nominal_batch=a.nominal_batch)   # configs/church.yml has the same model block
     else:
-        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=B, conv_math=a.conv_math)
+        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=B, conv_math=a.conv_math, nominal_batch=a.nominal_batch)
     model.setattr_layers(1)                     # get_h_num = 1
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
@@ -364,8 +367,8 @@ def main():
                                         if world > 1 and backend == "nccl" else None),
                        # A/B switches read by the library from the environment: a non-default kernel choice can never be
                        # benchmarked silently
-                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1")},
-                       "conv_math": a.conv_math},
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16", "ASYRP_SPLITK32", "ASYRP_CONV_IN", "ASYRP_CONV_OUT6")},
+                       "conv_math": a.conv_math, "nominal_batch": a.nominal_batch or 32},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
             "generation_only_images_per_s": B * world / (1e-3 * (20 * phases["generation_step_t>=t_edit(dual decoder)"] +

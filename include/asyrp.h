@@ -76,7 +76,13 @@ typedef struct asyrp_config {
   int32_t n_delta;                /* number of DeltaBlocks layer_0..layer_{n-1} (setattr_layers) */
   int32_t conv_math;              /* enum asyrp_conv_math: how the conv / 1x1 GEMMs are evaluated */
   int32_t num_classes;            /* iDDPM class_cond: 1000 adds the (unused) label_emb.weight key; else 0 */
-  int32_t reserved[6];
+  int32_t nominal_batch;          /* batch class of the engine: the batch at which tile shapes and split-K factors are priced (0 = 32,
+                                   * BASELINE config 2's per-GPU batch).  A property of the engine, never of a call: every call on
+                                   * this engine, whatever its B, runs the same kernels on an image, so an image alone equals its row
+                                   * of a batch bit for bit.  1 or 2 = the small class (single-image serving / the reference's
+                                   * bs_train = 1): more, smaller workgroups and K split up to 8 ways.  Results of different classes
+                                   * agree to fp32 rounding (as any two tile shapes do), not bitwise.  (Was reserved[0] = 0.) */
+  int32_t reserved[5];
 } asyrp_config;
 
 typedef struct asyrp_engine asyrp_engine;

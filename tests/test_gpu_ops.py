@@ -545,3 +545,79 @@ def test_barrier_free_1x1_kernel_statistics_epilogue(tile, H, W, Cin, Cout, offs
     got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
     want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("B,C0,C1,Cout,pro,res", [(2, 512, 0, 512, True, True), (1, 512, 512, 512, True, False), (3, 256, 0, 512, False, False),
+                                                   (2, 512, 256, 160, True, True)])
+def test_splitk_16x16_layers(B, C0, C1, Cout, pro, res, math):
+    """The launcher's choice for 3x3 layers on 16 x 16 maps (round 4): the 128-pixel K32 form with the K range split two ways and a
+    fixed-order reduce (bias / timestep vector / residual / GroupNorm partials in the reduce) -- concat input, ragged N tile,
+    against the fp32 reference, against the single-pass form (tile 8), and image-alone == image-in-batch bit for bit."""
+    x0 = hash_normal(f"sk16.x0.{B}.{C0}", (B, C0, 16, 16))
+    x1 = hash_normal(f"sk16.x1.{B}.{C1}", (B, C1, 16, 16)) if C1 else None
+    Cin = C0 + C1
+    w = hash_uniform(f"sk16.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"sk16.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform(f"sk16.g.{Cin}", (Cin,)), 0.1 * hash_uniform(f"sk16.be.{Cin}", (Cin,))) if pro else None
+    r = hash_normal(f"sk16.r.{B}.{Cout}", (B, Cout, 16, 16)) if res else None
+    ca = hash_normal(f"sk16.ca.{B}.{Cout}", (B, Cout))
+    kw = dict(x1=x1, gn=gn, silu=pro, residual=r, chan_add=ca)
+    got = hip_conv(x0, w, b, math=math, **kw)
+    want = ref_conv(x0, w, b, **kw)
+    if math == "f16x3":
+        assert_close(got, want, what="split-K 16x16", **TIGHT)
+        single = hip_conv(x0, w, b, math=math, tile=8, **kw)          # the same form without the split
+        assert_close(got, single, what="split-K vs single pass", rtol=1e-5, atol=2e-6)
+        i = B - 1
+        alone = hip_conv(x0[i:i + 1], w, b, x1=None if x1 is None else x1[i:i + 1], gn=gn, silu=pro,
+                         residual=None if r is None else r[i:i + 1], chan_add=ca[i:i + 1], math=math)
+        assert torch.equal(alone[0], got[i]), "split-K 16x16: result depends on the batch"
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,Cout,H,W", [(2, 128, 32, 32), (1, 256, 40, 24), (3, 64, 16, 16), (1, 128, 256, 256)])
+def test_first_convolution_stencil_kernel(B, Cout, H, W):
+    """conv_in.hip (round 4): the 3 -> Cout first convolution as an fp32 stencil -- plain fp32 products like the reference's own,
+    ragged patches, 128 / 256 / 64 output channels, the full 256 x 256 size; image alone == image in batch bit for bit."""
+    x = hash_normal(f"cin.x.{B}.{H}", (B, 3, H, W))
+    w = hash_uniform(f"cin.w.{Cout}", (Cout, 3, 3, 3), -1, 1) / 27 ** 0.5
+    b = 0.1 * hash_uniform(f"cin.b.{Cout}", (Cout,))
+    got = hip_conv(x, w, b, tile=17)
+    assert_close(got, ref_conv(x, w, b), what="conv_in stencil", rtol=1e-5, atol=2e-6)
+    if B > 1:
+        alone = hip_conv(x[B - 1:B], w, b, tile=17)
+        assert torch.equal(alone[0], got[B - 1]), "conv_in stencil: result depends on the batch"
+
+
+def test_first_convolution_stencil_kernel_refuses_other_shapes():
+    from asyrp_official_amd import _lib
+    x, w, b = _mk(1, 32, 64, 16, 3, "cin.bad")           # 32 input channels
+    with pytest.raises(_lib.AsyrpError):
+        hip_conv(x, w, b, tile=17)
+
+
+@pytest.mark.parametrize("H,W,Cout,offset", [(32, 32, 128, 0.0), (40, 24, 128, 30.0), (16, 16, 256, 5.0)])
+def test_first_convolution_stencil_kernel_statistics(H, W, Cout, offset):
+    """GroupNorm partials of the stencil kernel's epilogue (norm1 of the first block) incl. ragged patches and a large mean."""
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    B, Cin = 2, 3
+    x = hash_normal(f"cinst.x.{H}", (B, Cin, H, W))
+    w = hash_uniform(f"cinst.w.{Cout}", (Cout, Cin, 3, 3), -1, 1) / 27 ** 0.5
+    b = 0.1 * hash_uniform(f"cinst.b.{Cout}", (Cout,)) + offset
+    gam, bet = 1 + 0.1 * hash_uniform("cinst.g", (Cout,)), 0.1 * hash_uniform("cinst.be", (Cout,))
+    d = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = map(d, (x, w, b, gam, bet))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    sc, sh = torch.empty((B, Cout), device="cuda"), torch.empty((B, Cout), device="cuda")
+    _lib.check(lib.asyrp_op_conv2d_stats(0, _p(xd), Cin, B, H, W, _p(wd), _p(bd), Cout, 3, 17, _p(gd), _p(bed), 1e-6,
+                                         _p(y), _p(sc), _p(sh), None))
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x, w, b, padding=1)
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-5, atol=2e-6 * max(1.0, offset))
+    got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
+    assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)

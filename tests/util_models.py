@@ -15,9 +15,9 @@ def namespace_for(cfg):
         data=Namespace(image_size=cfg.resolution))
 
 
-def hip_model(cfg, sd, n_delta, device="cuda", max_batch=8, conv_math="f16x3"):
+def hip_model(cfg, sd, n_delta, device="cuda", max_batch=8, conv_math="f16x3", nominal_batch=0):
     from asyrp_official_amd import DDPM
-    m = DDPM(namespace_for(cfg), max_batch=max_batch, conv_math=conv_math)
+    m = DDPM(namespace_for(cfg), max_batch=max_batch, conv_math=conv_math, nominal_batch=nominal_batch)
     m.setattr_layers(n_delta)
     missing = m.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
