@@ -905,9 +905,19 @@ struct K32Cfg {
 //      writes alpha * acc to p.part[range][image][pixel][Cout]; launch_splitk_reduce adds the ranges in a fixed order with bias /
 //      timestep vector / residual and emits the GroupNorm partials.  For layers whose M x N offers fewer workgroups than the chip
 //      has slots (16 x 16 maps at B = 32: 256 workgroups of the 128-pixel form, one per CU).  No fused shortcut, no polyphase.
+// phase stamps (profiling library, ABL instantiation only): thread 0 of every workgroup records s_memrealtime (100 MHz) into
+// GemmArgs.dbg [workgroup][8]: 0 start, 1 first tile staged, 2 K loop done, 3 epilogue stores issued, 4 end, 5 = XCC_ID << 32 | HW_ID
+#define K32_STAMP(i) do { if (ABL && p.dbg && threadIdx.x == 0) p.dbg[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 template <class T, bool SC, bool ABL = false, int NP = 3, bool SPK = false>
 __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const GemmArgs p) {
   const int abl = ABL ? p.abl : 0;
+  K32_STAMP(0);
+  if (ABL && p.dbg && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.dbg[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+  }
   constexpr int NT = T::NT, BN = T::BN, PW = T::PW, TW = T::TW, PLANE = T::PLANE, WN = T::WN, WM = T::WM, TN = T::TN, BM = T::BM;
   constexpr int A_BYTES = T::A_BYTES, B_BYTES = T::B_BYTES, SLOT_BYTES = T::SLOT_BYTES, NA = T::NA, NU = T::NU, NSC = T::NSC;
   constexpr int WCH = BN / WN;                 // output channels per wave
@@ -1081,6 +1091,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   write_A(cb, cb & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  K32_STAMP(1);
 
   // one K = 32 step: 2 * (4 + TN) fragments, 12 * TN matrix instructions (16 and 48 on the main tile); pass order (x_lo*w_hi, x_hi*w_hi, x_hi*w_lo) as in every other tile.
   // A: lane address of row block 0 (x_hi); a_tm: byte pitch between row blocks; a_lo: byte offset of the x_lo planes
@@ -1223,47 +1234,64 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
   }
 
-  if (QUAD) {
+  K32_STAMP(2);
+  // ---- epilogue (round 4).  C/D layout of a 16 x 16 block: col = lane & 15 (channel), row = 4 * (lane >> 4) + r (pixel), i.e. a lane
+  // holds ONE channel of four pixels: stored from there, every value is its own global_store_dword (64 per wave, four 64-B
+  // segments each), and with the per-element bounds / residual branches hipcc put `s_waitcnt vmcnt(0)` in front of every one of
+  // them -- 64 serialized store round trips, 17 us of a 105-us tile (37 us with a residual; phase stamps,
+  // profiles/r04b_k32_phases.txt).  Now every row block goes through a wave-private LDS slab (16 pixels x WCH channels, all LDS
+  // is free after the K loop's last barrier; DS operations of a wave execute in order, no barrier) and comes back as float4 =
+  // four consecutive channels of one pixel: 16 global_store_dwordx4 per wave, 256 contiguous bytes per pixel, the residual read
+  // the same way (unconditional, clamped address) before the slab round trip.  The arithmetic per value is unchanged
+  // ((acc * alpha + (bias + chan_add)) + resid); the GroupNorm partials are summed in the new lane layout (double, fixed order:
+  // in-lane over row blocks and items -> shfl_xor over the lanes that share a channel quad -> wave rows through LDS).
+  constexpr int C4 = WCH / 4, EP = WCH + 4, NV = (16 * C4) / 64, RSTEP = 64 / C4;
+  static_assert(NV >= 1 && NV * 64 == 16 * C4, "slab items per lane");
+  static_assert((size_t)WM * BN * 16 + (size_t)T::NW * 16 * EP * 4 <= T::SMEM, "statistics rows + one slab per wave fit in the loop's LDS");
+  float* const ep = reinterpret_cast<float*>(smem + WM * BN * 16) + wave * (16 * EP);   // behind `red`
+  const int g = lane >> 4, c4 = lane % C4, prow = lane / C4;
+  const int nq = n0 + wn * WCH + c4 * 4;                 // this lane's channel quad after the slab round trip
+  auto slab_write = [&](int tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(4 * g + r) * EP + tn * 16 + r16] = acc[tm][tn][r] * p.alpha;
+    asm volatile("" ::: "memory");
+  };
+  auto slab_read = [&](int i) -> float4 {
+    return *reinterpret_cast<const float4*>(ep + (prow + i * RSTEP) * EP + c4 * 4);
+  };
+  if (QUAD || SPK) {
     // raw partial sums of this K range: part[range][image][pixel][Cout]; bias / residual / statistics belong to launch_splitk_reduce
-    const int gq = lane >> 4;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = n0 + wn * WCH + tn * 16 + r16;
-      if (n >= Cout) continue;
+    const int HWo = QUAD ? 64 : p.Hout * p.Wout;
+    {   // (launcher: Cout % 4 == 0, part 16-byte aligned -- k32_epilogue_ok)
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
-        const int py = wm * 4 + tm;
+        slab_write(tm);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int px = 4 * gq + r;
-          const int img = zo + (py >> 3) * 2 + (px >> 3);
-          if (img < p.Z) p.part[(((size_t)ks_id * p.Z + img) * 64 + (py & 7) * 8 + (px & 7)) * Cout + n] = acc[tm][tn][r] * p.alpha;
+        for (int i = 0; i < NV; ++i) {
+          const int m = prow + i * RSTEP;
+          int img, pixel;
+          bool ok;
+          if (QUAD) {
+            const int py = wm * 4 + tm;
+            img = zo + (py >> 3) * 2 + (m >> 3);
+            pixel = (py & 7) * 8 + (m & 7);
+            ok = (img < p.Z);
+          } else {
+            const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
+            img = zo;
+            pixel = oy * p.Wout + ox;
+            ok = (oy < p.Hout && ox < p.Wout);
+          }
+          const float4 a = slab_read(i);
+          if (ok && nq < Cout) *reinterpret_cast<float4*>(p.part + (((size_t)ks_id * p.Z + img) * HWo + pixel) * Cout + nq) = a;
         }
+        asm volatile("" ::: "memory");
       }
     }
     return;
   }
-  if (SPK) {
-    // raw partial sums of this K range: part[range][image][pixel][Cout] (the layout launch_splitk_reduce reads)
-    const int gq = lane >> 4, HWo = p.Hout * p.Wout;
-    float* __restrict__ part = p.part + ((size_t)ks_id * p.Z + zo) * HWo * Cout;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = n0 + wn * WCH + tn * 16 + r16;
-      if (n >= Cout) continue;
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 4 * gq + r;
-          const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
-          if (oy < p.Hout && ox < p.Wout) part[(size_t)(oy * p.Wout + ox) * Cout + n] = acc[tm][tn][r] * p.alpha;
-        }
-      }
-    }
-    return;
-  }
-  // ---- epilogue: C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r ----
   float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
   const float* __restrict__ rz = p.resid ? p.resid + (long long)zo * p.r_zo : nullptr;
   const float* __restrict__ cadd = p.chan_add ? p.chan_add + (long long)zo * p.ld_chan_add : nullptr;
@@ -1271,43 +1299,110 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const bool full = (n0 + BN <= Cout) && (oy0 + T::PH <= p.Hout) && (ox0 + PW <= p.Wout);
   double* const red = reinterpret_cast<double*>(smem);   // [WM wave rows][BN][2]; LDS is free after the last barrier
   const bool want_stats = (p.stats != nullptr);
-  const int g = lane >> 4;
+  // (launcher: ldo, ldr, Cout multiples of 4, out / resid 16-byte aligned -- k32_epilogue_ok)
+  {
+    const bool nok = full || (nq < Cout);
+    float add4[4];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + wn * WCH + tn * 16 + r16;
-    const bool nok = full || (n < Cout);
-    const float add = nok ? ((has_b ? p.bias[n] : 0.f) + (has_c ? cadd[n] : 0.f)) : 0.f;
-    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < 4; ++j) add4[j] = nok ? ((has_b ? p.bias[nq + j] : 0.f) + (has_c ? cadd[nq + j] : 0.f)) : 0.f;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    // item i of row block tm: block row m = prow + i * RSTEP -> output pixel, residual pixel, inside the image?
+    auto geom = [&](int tm, int i, int& pixel, int& rpix) -> bool {
+      const int m = prow + i * RSTEP;
+      const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
+      pixel = POLY ? (2 * oy + phy) * (2 * p.Wout) + 2 * ox + phx : oy * p.Wout + ox;
+      rpix = p.rups ? ((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) : pixel;
+      return oy < p.Hout && ox < p.Wout;
+    };
+    auto finish = [&](const float4& a, const float4& r, float4& v) {
+      v.x = (a.x + add4[0]) + r.x;
+      v.y = (a.y + add4[1]) + r.y;
+      v.z = (a.z + add4[2]) + r.z;
+      v.w = (a.w + add4[3]) + r.w;
+    };
+    auto stat4 = [&](const float4& v) {
+      s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
+      s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+      s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
+      s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+    };
+    if (full) {
+      // straight-line code (no per-element predicate, so hipcc counts vmcnt instead of draining it): the residual rows of block
+      // tm + 1 are requested right after block tm has left its accumulators for the slab, ahead of block tm's stores
+      float4 rv[2][NV];
+      auto load_rv = [&](int tm, float4 (&dst)[NV]) {
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      int pixel[4];
-      bool ok[4];
-      float rv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * g + r;                                   // row of the 16 x 16 block
-        const int oy = oy0 + (wm * 4 + tm) * FR + m / PW, ox = ox0 + m % PW;
-        ok[r] = nok && (full || (oy < p.Hout && ox < p.Wout));
-        pixel[r] = POLY ? (2 * oy + phy) * (2 * p.Wout) + 2 * ox + phx : oy * p.Wout + ox;
-        rv[r] = 0.f;
-        if (rz && ok[r]) rv[r] = p.rups ? rz[((oy >> 1) * (p.Wout >> 1) + (ox >> 1)) * p.ldr + n] : rz[pixel[r] * p.ldr + n];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (ok[r]) {
-          const float v = (acc[tm][tn][r] * p.alpha + add) + rv[r];
-          outz[pixel[r] * p.ldo + n] = v;
-          if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+        for (int i = 0; i < NV; ++i) {
+          int pixel, rpix;
+          (void)geom(tm, i, pixel, rpix);
+          dst[i] = *reinterpret_cast<const float4*>(rz + rpix * p.ldr + nq);
         }
+      };
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rv[0][i] = rv[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rz) load_rv(0, rv[0]);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        slab_write(tm);
+        if (rz && tm + 1 < 4) load_rv(tm + 1, rv[(tm + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          int pixel, rpix;
+          (void)geom(tm, i, pixel, rpix);
+          const float4 a = slab_read(i);
+          float4 v;
+          finish(a, rv[tm & 1][i], v);
+          *reinterpret_cast<float4*>(outz + pixel * p.ldo + nq) = v;
+          if (want_stats) stat4(v);
+        }
+        asm volatile("" ::: "memory");
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        int po[NV];
+        bool ok[NV];
+        float4 rv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          int pixel, rpix;
+          ok[i] = geom(tm, i, pixel, rpix) && nok;
+          po[i] = pixel * p.ldo + nq;
+          rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          // unconditional load from a clamped address: no per-element branch, the loads of a row block fly together
+          if (rz) rv[i] = *reinterpret_cast<const float4*>(rz + (ok[i] ? rpix * p.ldr + nq : 0));
+        }
+        slab_write(tm);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float4 a = slab_read(i);
+          float4 v;
+          finish(a, rv[i], v);
+          if (ok[i]) {
+            *reinterpret_cast<float4*>(outz + po[i]) = v;
+            if (want_stats) stat4(v);
+          }
+        }
+        asm volatile("" ::: "memory");
       }
     }
-    if (want_stats) {   // fixed-order reduction over the four row groups of the block, then over the wave rows below
-      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (g == 0) {
-        double* d = red + ((size_t)wm * BN + wn * WCH + tn * 16 + r16) * 2;
-        d[0] = s1;
-        d[1] = s2;
+    K32_STAMP(3);
+    if (want_stats) {   // fixed-order reduction over the lanes that hold the same channel quad, then over the wave rows below
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int off = C4; off < 64; off <<= 1) {
+          s1[j] += __shfl_xor(s1[j], off);
+          s2[j] += __shfl_xor(s2[j], off);
+        }
+      }
+      if (lane < C4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* d = red + ((size_t)wm * BN + wn * WCH + c4 * 4 + j) * 2;
+          d[0] = s1[j];
+          d[1] = s2[j];
+        }
       }
     }
   }
@@ -1327,6 +1422,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
         dst[1] = s2;
       }
     }
+  }
+  K32_STAMP(4);
+  if (ABL && p.dbg) {   // store drain time
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K32_STAMP(6);
   }
 }
 
@@ -1402,16 +1502,26 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// the float4 epilogue of the K32 kernel: output / residual rows and the channel count in whole, 16-byte aligned quads
+static bool k32_epilogue_ok(const GemmArgs& a) {
+  if ((a.Cout & 3) || (a.ldo & 3) || (a.o_zo & 3) || (((uintptr_t)a.out) & 15)) return false;
+  if (a.resid && ((a.ldr & 3) || (a.r_zo & 3) || (((uintptr_t)a.resid) & 15))) return false;
+  if (a.part && (((uintptr_t)a.part) & 15)) return false;
+  return true;
+}
 // the layers the K32 kernel takes over from the 8-wave 32x32x16 tile (everything else about the tile is the same)
 static bool k32_ok(const GemmArgs& a) {
+  if (!k32_epilogue_ok(a)) return false;
   if (a.s0 && (a.ups || (a.Cin2 & 31) || a.Cin2 < 32)) return false;   // fused shortcut: an even number of raw slices
   return a.ks == 3 && a.stride == 1 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
 }
 static bool k32s2_ok(const GemmArgs& a) {
+  if (!k32_epilogue_ok(a)) return false;
   return a.ks == 3 && a.stride == 2 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && (a.Cin & 31) == 0 && a.Cin >= 32 && is_vec(a);
 }
 // split-K on the plain K32 forms (GemmArgs.sk, .part, .tile = the form): whole K = 32 steps per range
 static bool k32spk_ok(const GemmArgs& a) {
+  if (!k32_epilogue_ok(a)) return false;
   if (!(a.tile == XT_256x128K32 || a.tile == XT_128x128K32 || a.tile == XT_64x128K32)) return false;
   if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && !a.poly && !a.rups && a.sk >= 2 && a.part)) return false;
   return (a.Cin & 31) == 0 && ((a.Cin / XKC) % (2 * a.sk)) == 0 && is_vec(a);
@@ -1505,11 +1615,13 @@ static int requested_tile_x(const GemmArgs& a) {
 // the tile actually launched: ragged channel counts (conv_in: Cin = 3) use scalar-gather staging, compiled for two shapes
 // polyphase launch (GemmArgs.poly): nearest x2 + 3x3 as four 2x2-tap convolutions on the source grid (K32Cfg<8, 2, 16, 1, 2>)
 static bool k32up_ok(const GemmArgs& a) {
+  if (!k32_epilogue_ok(a)) return false;
   return a.poly && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && a.sk <= 1 && !a.resid && (a.Cin & 31) == 0 && a.Cin >= 32 &&
          a.Hin == a.Hout && a.Win == a.Wout && a.w_phase > 0 && is_vec(a);
 }
 // quad form (split-K over four-image groups) for the 8 x 8 layers: dense per-image tensors, an even number of chunks per K range
 static bool k32quad_ok(const GemmArgs& a) {
+  if (!k32_epilogue_ok(a)) return false;
   if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && !a.abl && !a.poly && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8)) return false;
   if (a.sk < 2 || !a.part || (a.Cin & 31) || ((a.Cin / XKC) % (2 * a.sk)) != 0 || !is_vec(a)) return false;
   if (a.a0_zo != 64LL * a.lda0 || (a.a1 && a.a1_zo != 64LL * a.lda1)) return false;

@@ -186,6 +186,9 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   // chunk c lives in register set c & 1 until it is staged; loads past the last chunk re-read it (static load counts)
   gload(0, S0{});
   gload(min(1, nch - 1), S1{});
+  __syncthreads();   // the scale / shift rows in Ps were written by other waves (without this barrier waves 1-3 staged chunk 0 from
+                     // whatever the LDS held: a few-per-mille run-to-run difference in some tiles of some images, found in round 4
+                     // by running the same batch twice -- scripts/batch_invariance_probe.py)
   stage(0, 0, S0{});
   __syncthreads();
   for (int chunk = 0; chunk < nch; chunk += 2) {   // nch is even (launcher: Cin % 32 == 0)

@@ -2981,9 +2981,26 @@ __global__ void fill_hash_kernel(float* p, long long n, unsigned seed, float sca
 }
 
 #ifdef ASYRP_BENCH_HOOKS   // the profiling library only (libasyrp_hip_bench.so, scripts/conv_bench.py)
+static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                           int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                           void* stream, unsigned long long* stamps_host, int stamps_cap);
 int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
                         void* stream) {
+  return conv_bench_impl(device, B, H, W, C0, C1, Cout, ksize, stride, upsample, prologue, residual, conv_math, tile, abl, iters,
+                         ms_out, stream, nullptr, 0);
+}
+// the same, plus the phase stamps of the LAST launch ([workgroup][8] s_memrealtime ticks, K32_STAMP in conv_f16x3.hip; abl != 0)
+int asyrp_op_conv_stamps(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                         unsigned long long* stamps_host, int stamps_cap) {
+  return conv_bench_impl(device, B, H, W, C0, C1, Cout, ksize, stride, upsample, prologue, residual, conv_math, tile, abl, iters,
+                         ms_out, nullptr, stamps_host, stamps_cap);
+}
+// abl bit 6 (64): the launch also emits GroupNorm partial sums (as conv1 of every block does)
+static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                           int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                           void* stream, unsigned long long* stamps_host, int stamps_cap) {
   if (B < 1 || iters < 1 || !ms_out) return fail(ASYRP_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
@@ -3023,7 +3040,19 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   g.chan_add = ca; g.ld_chan_add = Cout;
   if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
   g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
-  g.math = MATH_F32; g.tile = tile; g.abl = abl;
+  g.math = MATH_F32; g.tile = tile; g.abl = abl & ~64;
+  if (abl & 64) {
+    float* st;
+    TRY(dalloc((size_t)B * 4 * ((Ho + 7) / 8) * ((Wo + 7) / 8) * Cout * 4, &st, 0.f, 14));   // >= [image][M block][Cout][2] doubles for any tile
+    g.stats = reinterpret_cast<double*>(st);
+  }
+  unsigned long long* dbg = nullptr;
+  if (stamps_host && stamps_cap > 0) {
+    HIPCHK(hipMalloc(&dbg, (size_t)stamps_cap * 64));
+    tmp.push_back(dbg);
+    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)stamps_cap * 64, s));
+    g.dbg = dbg;
+  }
   if (conv_math == ASYRP_MATH_F16X3 || conv_math == ASYRP_MATH_F16) {
     g.np = (conv_math == ASYRP_MATH_F16) ? 1 : 3;
     float* xp;
@@ -3073,6 +3102,7 @@ int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cou
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (dbg && se == hipSuccess) (void)hipMemcpy(stamps_host, dbg, (size_t)stamps_cap * 64, hipMemcpyDeviceToHost);
   for (void* p : tmp) (void)hipFree(p);
   if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench launch: ") + hipGetErrorString(le));
   if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench sync: ") + hipGetErrorString(se));

@@ -61,6 +61,7 @@ struct GemmArgs {
   _Float16* o16h; _Float16* o16l; _Float16* vth; _Float16* vtl; int ld16, v_mod, v_off, v_dh; long long o16_zo, vt_zo;
   int nz;                         // nominal batch of the engine's batch class (tile / split-K rules are priced at it, never at Z); 0 = 32
   int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
+  unsigned long long* dbg;        // profiling library only: phase stamps [workgroup][8] of the K32 ablation instantiation (null in the product)
 };
 
 enum { MATH_F16X3 = 0, MATH_F32 = 1 };

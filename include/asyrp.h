@@ -296,6 +296,12 @@ int asyrp_op_attention(int device, const float* qkv, int B, int C, int T, int he
 int asyrp_op_conv_bench(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
                         void* stream);
+/* The same launch, plus the phase stamps of the last one: stamps_host [stamps_cap >= workgroups][8] s_memrealtime ticks (100 MHz)
+ * of igemm_f16x3_k32_kernel's ablation instantiation (abl != 0; abl bit 6 = also emit GroupNorm partial sums): 0 start, 1 first
+ * tile staged, 2 K loop done, 3 epilogue stores issued, 4 end, 5 = XCC_ID << 32 | HW_ID, 6 stores drained (scripts/k32_phases.py). */
+int asyrp_op_conv_stamps(int device, int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int upsample,
+                         int prologue, int residual, int conv_math, int tile, int abl, int iters, float* ms_out,
+                         unsigned long long* stamps_host, int stamps_cap);
 /* attn_planes_kernel on synthetic planes: average launch time over `iters` launches and the phase stamps of the last one,
  * stamps_host [B*heads*T/32][8] s_memrealtime ticks (100 MHz): 0 start, 1 Q staged, 2 S^T done, 3 P in LDS, 4 last PV item done,
  * 5 end (scripts/attn_phases.py). */
