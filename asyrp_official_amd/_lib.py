@@ -64,7 +64,7 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 # the profiling library (same sources + -DASYRP_BENCH_HOOKS): scripts/conv_bench.py only, never loaded by the package
-BENCH_LIB_PATH = os.path.join(_HERE, "libasyrp_hip_bench.so")
+BENCH_LIB_PATH = os.environ.get("ASYRP_BENCH_LIB") or os.path.join(_HERE, "libasyrp_hip_bench.so")   # (override: A/B builds of the profiling library)
 BENCH_SIGS = {"asyrp_op_conv_bench": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P]),
               "asyrp_op_conv_stamps": (C.c_int, [_I] * 16 + [C.POINTER(C.c_float), _P, _I]),
               "asyrp_op_attention_phases": (C.c_int, [_I] * 7 + [C.POINTER(C.c_float), _P, _P]),
