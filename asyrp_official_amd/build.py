@@ -10,7 +10,8 @@ LIB = PRODUCT_LIB = os.path.join(HERE, "libasyrp_hip.so")
 BENCH_LIB = os.path.join(HERE, "libasyrp_hip_bench.so")
 SOURCES = ["kernels.hip", "conv_f16x3.hip", "conv_out.hip", "conv_in.hip", "gemm1x1.hip", "attention.hip", "backward.hip", "engine.hip"]
 DEPS = SOURCES + ["kernels.h", os.path.join("..", "..", "include", "asyrp.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-comment"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-comment",
+         "-fvisibility=hidden"]   # exports = the extern "C" entry points of include/asyrp.h (visibility pragma there)
 
 
 def _hipcc():

@@ -638,9 +638,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_kernel(const GemmA
     // fragment-major tile order of kernels.h frag_off (pixels % 16 == 0, ld16 % 32 == 0: the launcher of the planes path).  Accumulator
     // elements 4j .. 4j+3 of a lane are 4 consecutive pixels of one channel: one 8-byte store per plane in the transposed part.
     _Float16* __restrict__ oh = p.o16h + (long long)zo * p.o16_zo;
-    _Float16* __restrict__ ol = p.o16l + (long long)zo * p.o16_zo;
+    // (the lo planes are absent in the single-product mode: no pointer arithmetic on null -- `if (ol)` below must see a real null
+    //  for every image, not null + zo * stride)
+    _Float16* __restrict__ ol = p.o16l ? p.o16l + (long long)zo * p.o16_zo : nullptr;
     _Float16* __restrict__ vh = p.vth + (long long)zo * p.vt_zo;
-    _Float16* __restrict__ vl = p.vtl + (long long)zo * p.vt_zo;
+    _Float16* __restrict__ vl = p.vtl ? p.vtl + (long long)zo * p.vt_zo : nullptr;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int n = n0 + (wn * TN + tn) * 32 + (lane & 31);

@@ -2355,16 +2355,8 @@ int asyrp_train_backward(asyrp_engine* e, int64_t tape_id, const float* d_et_mod
     return fail(ASYRP_ESTATE, "asyrp_train_backward: stale tape id (a later asyrp_train_forward replaced the recorded step; the "
                               "engine keeps ONE pending step)");
   if (!d_et_mod || n_grads < 0 || (n_grads && (!keys || !grads))) return fail(ASYRP_EINVAL, "bad argument");
-  Tape& tp = e->tape;
-  const int B = tp.B;
-  HIPCHK(hipSetDevice(e->device));
-  Ctx c{e, (hipStream_t)stream, B};
-  TRY(bind_stream(e, c.s));
-  struct Guard {   // the tape is consumed whatever happens
-    asyrp_engine* e;
-    ~Guard() { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); }
-  } guard{e};
-  {   // every requested key must be a parameter of layer_0 this pass produces a gradient for
+  {   // every requested key must be a parameter of layer_0 this pass produces a gradient for (checked BEFORE the tape is touched: a
+      // refused call leaves the pending step intact -- ADVICE r03)
     const bool idd = e->cfg.family == ASYRP_FAMILY_IDDPM;
     static const char* const kd[] = {"layer_0.conv1.weight", "layer_0.conv1.bias", "layer_0.temb_proj.weight", "layer_0.temb_proj.bias",
                                      "layer_0.norm2.weight", "layer_0.norm2.bias", "layer_0.conv2.weight", "layer_0.conv2.bias"};
@@ -2380,6 +2372,15 @@ int asyrp_train_backward(asyrp_engine* e, int64_t tape_id, const float* d_et_mod
       if (!known) return fail(ASYRP_EKEY, std::string("asyrp_train_backward: no gradient for key ") + (keys[i] ? keys[i] : "(null)"));
     }
   }
+  Tape& tp = e->tape;
+  const int B = tp.B;
+  HIPCHK(hipSetDevice(e->device));
+  Ctx c{e, (hipStream_t)stream, B};
+  TRY(bind_stream(e, c.s));
+  struct Guard {   // from here on the tape is consumed whatever happens
+    asyrp_engine* e;
+    ~Guard() { e->pool.reclaim(); e->pool.release_held(); e->tape.clear(); }
+  } guard{e};
   auto out_ptr = [&](const std::string& key) -> float* {
     for (int i = 0; i < n_grads; ++i)
       if (key == keys[i]) return grads[i];

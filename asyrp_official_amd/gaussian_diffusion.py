@@ -100,14 +100,18 @@ def sampler_update(x, model_out, rows, *, noise=None, want_sample=True, want_xst
     if noise is not None:
         noise = _gpu_f32(noise, "noise")
         assert noise.shape == x.shape
+    for name, t_ in (("model output", model_out), ("noise", noise)):   # raw pointers are handed to x's device: they must live there
+        if t_ is not None and t_.device != x.device:
+            raise AsyrpDeviceError(f"{name} is on {t_.device}, x on {x.device}")
     sample = torch.empty_like(x) if want_sample else None
     xstart = torch.empty_like(x) if want_xstart else None
     logvar = torch.empty_like(x) if want_log_variance else None
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     lib = _lib.load()
-    _lib.check(lib.asyrp_sampler_update(x.device.index, ptr(x), ptr(model_out), int(model_out.shape[1]), B, Cx, HW,
-                                        rows.ctypes.data_as(C.c_void_p), ptr(noise), ptr(sample), ptr(xstart), ptr(logvar),
-                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    with torch.cuda.device(x.device):   # the entry point selects x's device for the calling thread: restore the caller's afterwards
+        _lib.check(lib.asyrp_sampler_update(x.device.index, ptr(x), ptr(model_out), int(model_out.shape[1]), B, Cx, HW,
+                                            rows.ctypes.data_as(C.c_void_p), ptr(noise), ptr(sample), ptr(xstart), ptr(logvar),
+                                            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
     return sample, xstart, logvar
 
 
@@ -124,11 +128,44 @@ class GaussianDiffusion:
         self.schedule = SamplerSchedule(betas)
         self.num_timesteps = self.schedule.T
         self.betas, self.alphas_cumprod = self.schedule.beta, self.schedule.abar
+        # The schedule tables scripts read off the vendored class (float64 numpy, models/guided_diffusion/gaussian_diffusion.py:143-176),
+        # derived here from beta / alpha_bar; the sampling path itself uses SamplerSchedule's coefficient rows, not these.
+        ab, be = np.asarray(self.alphas_cumprod, dtype=np.float64), np.asarray(self.betas, dtype=np.float64)
+        self.alphas_cumprod_prev = np.concatenate([[1.0], ab[:-1]])
+        self.alphas_cumprod_next = np.concatenate([ab[1:], [0.0]])
+        self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod = np.sqrt(ab), np.sqrt(1.0 - ab)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - ab)
+        self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / ab), np.sqrt(1.0 / ab - 1.0)
+        self.posterior_variance = be * (1.0 - self.alphas_cumprod_prev) / (1.0 - ab)
+        self.posterior_log_variance_clipped = np.log(np.concatenate([self.posterior_variance[1:2], self.posterior_variance[1:]]))
+        self.posterior_mean_coef1 = be * np.sqrt(self.alphas_cumprod_prev) / (1.0 - ab)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(1.0 - be) / (1.0 - ab)
+
+    # ---- small helpers of the vendored class (plain torch on the tensors' own device; not on the sampling path) ------------------
+    @staticmethod
+    def _table(arr, t, like):
+        v = torch.from_numpy(np.asarray(arr)).to(device=like.device, dtype=torch.float32)[t.long()]
+        return v.view(-1, *([1] * (like.dim() - 1)))
+
+    def _scale_timesteps(self, t):
+        return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        return self._table(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - self._table(self.sqrt_recipm1_alphas_cumprod, t, x_t) * eps
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return self._table(self.sqrt_alphas_cumprod, t, x_start) * x_start + self._table(self.sqrt_one_minus_alphas_cumprod, t, x_start) * noise
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        mean = self._table(self.posterior_mean_coef1, t, x_t) * x_start + self._table(self.posterior_mean_coef2, t, x_t) * x_t
+        var = self._table(self.posterior_variance, t, x_t).expand(x_t.shape)
+        logvar = self._table(self.posterior_log_variance_clipped, t, x_t).expand(x_t.shape)
+        return mean, var, logvar
 
     # ---- shared plumbing ------------------------------------------------------------------------------------------------
     def _model_output(self, model, x, t, model_kwargs):
-        ts = t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
-        out = model(x, ts, **(model_kwargs or {}))
+        out = model(x, self._scale_timesteps(t), **(model_kwargs or {}))
         out = out[0] if isinstance(out, (tuple, list)) else out
         want = x.shape[1] * (2 if self.model_var_type == "learned_range" else 1)
         if out.shape[1] != want:
@@ -142,8 +179,8 @@ class GaussianDiffusion:
         assert tt.shape == (x.shape[0],)
         out = self._model_output(model, x, t, model_kwargs)
         rows = self.schedule.rows(kind, tt, var_type=self.model_var_type, clip=clip_denoised, eta=eta, noisy=noisy)
-        if noisy and noise is None and bool((rows[:, 4] != 0).any()):
-            noise = torch.randn_like(x)
+        if noisy and noise is None:
+            noise = torch.randn_like(x)     # drawn unconditionally, as the vendored class does (its RNG stream also advances at t == 0)
         if not noisy or not bool((rows[:, 4] != 0).any()):
             noise = None
         if denoised_fn is None:

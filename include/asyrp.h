@@ -87,6 +87,11 @@ typedef struct asyrp_config {
 
 typedef struct asyrp_engine asyrp_engine;
 
+/* The library is built with -fvisibility=hidden: the entry points declared in this header are its whole dynamic symbol table
+ * (besides the HIP kernel stubs the runtime needs).  (The opaque handle type above stays outside the pragma.) */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
 #define ASYRP_ABI_VERSION 7
 int asyrp_abi_version(void);
@@ -311,6 +316,9 @@ int asyrp_op_gemm1x1_phases(int device, int B, int H, int Cin, int Cout, int pro
                             unsigned long long* stamps_host, void* stream);
 #endif
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 evidence on one MI355X box: parity tests, the DRIVER's bench command, rocprofv3 kernel stats of that command, HBM traffic
+# End-of-round evidence on one MI355X box: parity tests, the DRIVER's bench command, rocprofv3 kernel stats of that command, HBM traffic
 # (PMC, separate passes) of EVERY kernel family on the shipped library, the fast-mode line with its own traffic, the other
-# BASELINE configs, B=1.  usage: scripts/gpu_final_r03.sh <tag>
+# BASELINE configs, B=1.  usage: scripts/gpu_evidence.sh <tag>   (profiles/<tag>_* are then copied by hand)
 set -u
-TAG=${1:-rd3final}
+TAG=${1:-evidence}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -611,6 +611,106 @@ def run_config4(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_config3_full(out):
+    """BASELINE config 3 END TO END through the REFERENCE: AFHQ-Dog iDDPM + the SHIPPED `dog_happy` DeltaBlock,
+    B=1, a seeded image -> 39 DDIM inversion steps (diffusion_latent.py:1034-1045, learn_sigma) -> x_T -> 40 Asyrp steps, t_edit=444.
+    Stored: x_T, x_edit, and teacher-forced inversion steps at full size (first, a middle one, the last)."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    torch.set_num_threads(os.cpu_count())
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    ck = torch.load(os.path.join(REF, "checkpoint", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"), map_location="cpu",
+                    weights_only=False)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    m = ref_iddpm(AFHQ, sd, 1)
+    x0 = hash_uniform("config3.x0", (1, 3, 256, 256), seed=4321)          # an image in [-1, 1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    seq, seq_next = _seq40()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", learn_sigma=True)
+    one = torch.ones(1)
+    g = {}
+    with torch.no_grad():
+        x = x0.clone()
+        n = len(seq) - 1
+        for k, (i, j) in enumerate(zip(seq_next[1:], seq[1:])):
+            xin = x
+            x, x0t, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0, **kw)
+            if k == 0:
+                g["inv_first.xt_next"], g["inv_first.x0_t"] = x.clone(), x0t.clone()
+            if k == n // 2:
+                g["inv_mid.t"] = torch.tensor([float(i), float(j)])
+                g["inv_mid.x_t"], g["inv_mid.xt_next"] = xin.clone(), x.clone()
+            if k == n - 1:
+                g["inv_last.x_t"], g["inv_last.x0_t"] = xin.clone(), x0t.clone()
+        g["x_T"] = x.clone()
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=444, hs_coeff=(1.0, 1.0), **kw)
+        g["x_edit"] = x.clone()
+    for k, v in sd.items():
+        if k.startswith("layer_0."):
+            g["param." + k] = v.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_imagenet_step(out):
+    """BASELINE config 5, one teacher-forced dual-decoder STEP at full size through the REFERENCE:
+    i_DDPM('IMAGENET') (1024-channel bottleneck), B=1, utils/diffusion_utils.py denoising_step with learn_sigma=True
+    (the 6-channel head is split, :47-51) and the DDIM update, t = 700 -> 674 with index=0, t_edit=500."""
+    from models.improved_ddpm.script_util import i_DDPM
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd, x = imagenet_state_dict()
+    m = i_DDPM("IMAGENET")
+    m.setattr_layers(1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval()
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    g = {}
+    with torch.no_grad():
+        xn, x0t, dh, mh = denoising_step(x, t=torch.ones(1) * 700.0, t_next=torch.ones(1) * 674.0, models=m, logvars=np.zeros(1000),
+                                         b=betas, sampling_type="ddim", eta=0.0, learn_sigma=True, index=0, t_edit=500,
+                                         hs_coeff=(1.0, 1.0))
+    g["step.xt_next"], g["step.x0_t"], g["step.delta_h"] = xn, x0t, dh
+    g["probe.x"] = x[0, 0, 0, :8].clone()
+    g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_config1_b2(out):
+    """A BATCH pinned to the reference directly: BASELINE config 1's model (CelebA-HQ DDPM + the shipped
+    `smiling` DeltaBlock), B = 2 with two DIFFERENT images, teacher-forced steps executed by the REFERENCE on the whole batch:
+    the first inversion step, a middle inversion step, an edited generation step (dual decoder) and an un-edited one."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd = config1_state_dict()
+    m = ref_model(CELEBA, sd, n_delta=1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", eta=0.0)
+    two = torch.ones(2)
+    g = {}
+    with torch.no_grad():
+        x0 = torch.cat([hash_uniform("config1b2.x0a", (1, 3, 256, 256), seed=11), hash_uniform("config1b2.x0b", (1, 3, 256, 256), seed=12)])
+        xn, x0t, _, _ = denoising_step(x0, t=two * 0, t_next=two * 25, **kw)
+        g["inv0.xt_next"], g["inv0.x0_t"] = xn.clone(), x0t.clone()
+        xm = torch.cat([hash_normal("config1b2.xma", (1, 3, 256, 256), seed=13), hash_normal("config1b2.xmb", (1, 3, 256, 256), seed=14)])
+        xn, _, _, _ = denoising_step(xm, t=two * 512, t_next=two * 537, **kw)
+        g["inv512.xt_next"] = xn.clone()
+        xn, x0t, dh, _ = denoising_step(xm, t=two * 768, t_next=two * 742, index=0, t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        g["gen768.xt_next"], g["gen768.x0_t"], g["gen768.delta_h"] = xn.clone(), x0t.clone(), dh.clone()
+        xn, _, dh, _ = denoising_step(xm, t=two * 307, t_next=two * 281, index=0, t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+        assert dh is None
+        g["gen307.xt_next"] = xn.clone()
+    for k, v in sd.items():
+        if k.startswith("layer_0."):
+            g["param." + k] = v.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
@@ -624,7 +724,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers", "imagenet", "config4"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers", "imagenet", "config4", "config3_full", "imagenet_step", "config1_b2"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
@@ -654,3 +754,9 @@ if __name__ == "__main__":
         run_imagenet(os.path.join(HERE, "imagenet_adm.npz"))
     if a.only in (None, "config4"):
         run_config4(os.path.join(HERE, "config4_church_gothic.npz"))
+    if a.only in (None, "config1_b2"):
+        run_config1_b2(os.path.join(HERE, "config1_b2_celeba_smiling.npz"))
+    if a.only in (None, "imagenet_step"):
+        run_imagenet_step(os.path.join(HERE, "imagenet_adm_step.npz"))
+    if a.only in (None, "config3_full"):
+        run_config3_full(os.path.join(HERE, "config3_afhq_full.npz"))

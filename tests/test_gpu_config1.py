@@ -61,19 +61,23 @@ def test_config1_teacher_forced_steps_full_size(config1):
     xn, x0t, dh, _ = eng.ddim_step(x0, 0, 25)
     assert dh is None
     assert_close(xn, g["inv_first.xt_next"], what="inversion 0->25 xt_next")
+    print("inversion 0->25 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["inv_first.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["inv_first.x0_t"], atol=1e-4 * _amp(b, 0), what="inversion 0->25 x0_t")
     xn, x0t, _, _ = eng.ddim_step(g["inv_last.x_t"].cuda(), 973, 999)
     assert_close(xn, g["x_T"], what="inversion 973->999 xt_next (= x_T)")
+    print("inversion 973->999 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["inv_last.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["inv_last.x0_t"], atol=1e-4 * _amp(b, 973), what="inversion 973->999 x0_t")
     # first generation step: dual decoder with the shipped smiling DeltaBlock
     xn, x0t, dh, _ = eng.ddim_step(g["x_T"].cuda(), 999, 973, apply_edit=True, **ek)
     assert_close(dh, g["gen999.delta_h"], what="t=999 delta_h (shipped DeltaBlock)")
     assert_close(xn, g["gen999.xt_next"], what="t=999 xt_next")
+    print("t=999 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["gen999.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["gen999.x0_t"], atol=1e-4 * _amp(b, 999), what="t=999 x0_t")
     # last edited step (t = 512 >= t_edit), then the first step below t_edit (single decoder, et_mod == et)
     xn, x0t, dh, _ = eng.ddim_step(g["gen512.x_t"].cuda(), 512, 486, apply_edit=True, **ek)
     assert_close(dh, g["gen512.delta_h"], what="t=512 delta_h")
     assert_close(xn, g["gen512.xt_next"], what="t=512 xt_next")
+    print("t=512 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["gen512.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["gen512.x0_t"], atol=1e-4 * _amp(b, 512), what="t=512 x0_t")
     xn, _, dh, _ = eng.ddim_step(g["gen512.xt_next"].cuda(), 486, 461, apply_edit=False, **ek)
     assert dh is None
@@ -85,6 +89,7 @@ def test_config1_teacher_forced_steps_full_size(config1):
     # eta = 1 steps of the stochastic tail (t < t_addnoise = 167), reference's own noise
     xn, x0t, _, _ = eng.ddim_step(g["eta153.x_t"].cuda(), 153, 128, eta=1.0, noise=noise[0].cuda(), apply_edit=False, **ek)
     assert_close(xn, g["eta153.xt_next"], what="eta=1 t=153 xt_next")
+    print("eta=1 t=153 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["eta153.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["eta153.x0_t"], atol=1e-4 * _amp(b, 153), what="eta=1 t=153 x0_t")
     xn, _, _, _ = eng.ddim_step(g["eta0.x_t"].cuda(), 0, -1, eta=1.0, noise=noise[6].cuda(), apply_edit=False, **ek)
     assert_close(xn, g["x_edit_noise"], what="eta=1 t=0 -> -1 xt_next (= x_edit with noise)")
@@ -150,6 +155,7 @@ def test_config3_afhq_teacher_forced_and_free_running():
     xn, x0t, dh, _ = eng.ddim_step(x_T, 999, 973, apply_edit=True, **ek)
     assert_close(dh, g["gen999.delta_h"], what="t=999 delta_h (shipped dog_happy DeltaBlock)")
     assert_close(xn, g["gen999.xt_next"], what="t=999 xt_next")
+    print("t=999 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["gen999.x0_t"]))   # (reported next to the scaled verdict)
     assert_close(x0t, g["gen999.x0_t"], atol=1e-4 * _amp(b, 999), what="t=999 x0_t")
     xn, _, dh, _ = eng.ddim_step(g["gen461.x_t"].cuda(), 461, 435, apply_edit=True, **ek)     # 461 >= t_edit = 444
     assert_close(dh, g["gen461.delta_h"], what="t=461 delta_h")
@@ -191,3 +197,80 @@ def test_config4_church_gothic_teacher_forced_steps():
         print(f"config4 t={t} xt_next", err_stats(xn, g[f"gen{t}.xt_next"]))
         assert_close(xn, g[f"gen{t}.xt_next"], what=f"t={t} xt_next")
         assert_close(x0t, g[f"gen{t}.x0_t"], atol=1e-4 * _amp(b, t), what=f"t={t} x0_t")
+
+
+def test_config1_batch_of_two_pinned_to_the_reference():
+    """A batch pinned to the reference DIRECTLY: B = 2, two different images, teacher-forced steps executed by
+    the reference on the whole batch (tests/golden/make_golden.py run_config1_b2) -- until now every full-size reference fixture
+    was B = 1 and batches were pinned only through the bitwise alone-vs-in-batch invariance."""
+    g = _need("config1_b2_celeba_smiling.npz")
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    m = hip_model(CELEBA, sd, 1, max_batch=2)
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    x0 = torch.cat([hash_uniform("config1b2.x0a", (1, 3, 256, 256), seed=11), hash_uniform("config1b2.x0b", (1, 3, 256, 256), seed=12)]).cuda()
+    xm = torch.cat([hash_normal("config1b2.xma", (1, 3, 256, 256), seed=13), hash_normal("config1b2.xmb", (1, 3, 256, 256), seed=14)]).cuda()
+    eng = m._ready_engine(x0)
+    ek = dict(index=0, hs_coeff=(1.0, 1.0))
+    xn, x0t, _, _ = eng.ddim_step(x0, 0, 25)
+    assert_close(xn, g["inv0.xt_next"], what="B=2 inversion 0->25 xt_next")
+    print("B=2 inversion 0->25 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["inv0.x0_t"]))   # (VERDICT r03 3d: reported next to the scaled verdict)
+    assert_close(x0t, g["inv0.x0_t"], atol=1e-4 * _amp(b, 0), what="B=2 inversion 0->25 x0_t")
+    xn, _, _, _ = eng.ddim_step(xm, 512, 537)
+    assert_close(xn, g["inv512.xt_next"], what="B=2 inversion 512->537 xt_next")
+    xn, x0t, dh, _ = eng.ddim_step(xm, 768, 742, apply_edit=True, **ek)
+    assert_close(dh, g["gen768.delta_h"], what="B=2 t=768 delta_h")
+    assert_close(xn, g["gen768.xt_next"], what="B=2 t=768 xt_next (dual decoder)")
+    print("B=2 t=768 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["gen768.x0_t"]))   # (VERDICT r03 3d: reported next to the scaled verdict)
+    assert_close(x0t, g["gen768.x0_t"], atol=1e-4 * _amp(b, 768), what="B=2 t=768 x0_t")
+    st = err_stats(x0t, g["gen768.x0_t"])      # the same tensor against the UNSCALED north-star tolerance (reported, VERDICT r03 3d)
+    print("B=2 t=768 x0_t vs unscaled rtol 1e-3 / atol 1e-4:", st)
+    xn, _, dh, _ = eng.ddim_step(xm, 307, 281, apply_edit=False, **ek)
+    assert dh is None
+    assert_close(xn, g["gen307.xt_next"], what="B=2 t=307 xt_next (below t_edit)")
+    # the two rows really are different images
+    assert float((g["inv0.xt_next"][0] - g["inv0.xt_next"][1]).abs().max()) > 0.1
+
+
+def test_config3_afhq_inversion_and_whole_edit_vs_reference():
+    """BASELINE config 3 END TO END against the reference (make_golden.py run_config3_full): 39 inversion steps
+    with learn_sigma at full size (teacher-forced first / middle / last step strict, free-running x_T strict as for config 1),
+    then the 40 Asyrp steps with the shipped dog_happy DeltaBlock (free-running x_edit bounded relative to the trajectory scale)."""
+    from asyrp_official_amd import i_DDPM, run_edit
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    g = _need("config3_afhq_full.npz")
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    for k in list(g):
+        if k.startswith("param."):
+            sd[k[len("param."):]] = g[k]
+    m = i_DDPM("AFHQ", max_batch=2)
+    m.setattr_layers(1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda().eval()
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    x0 = hash_uniform("config3.x0", (1, 3, 256, 256), seed=4321).cuda()
+    eng = m._ready_engine(x0)
+    ek = dict(learn_sigma=True)
+    xn, x0t, dh, _ = eng.ddim_step(x0, 0, 25, **ek)
+    assert dh is None
+    assert_close(xn, g["inv_first.xt_next"], what="AFHQ inversion 0->25 xt_next")
+    print("AFHQ inversion 0->25 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["inv_first.x0_t"]))   # (VERDICT r03 3d: reported next to the scaled verdict)
+    assert_close(x0t, g["inv_first.x0_t"], atol=1e-4 * _amp(b, 0), what="AFHQ inversion 0->25 x0_t")
+    ti, tj = int(g["inv_mid.t"][0]), int(g["inv_mid.t"][1])
+    xn, _, _, _ = eng.ddim_step(g["inv_mid.x_t"].cuda(), ti, tj, **ek)
+    assert_close(xn, g["inv_mid.xt_next"], what=f"AFHQ inversion {ti}->{tj} xt_next")
+    xn, x0t, _, _ = eng.ddim_step(g["inv_last.x_t"].cuda(), 973, 999, **ek)
+    assert_close(xn, g["x_T"], what="AFHQ inversion 973->999 xt_next (= x_T)")
+    print("AFHQ inversion 973->999 x0_t: unscaled rtol 1e-3 / atol 1e-4 ->", err_stats(x0t, g["inv_last.x0_t"]))   # (VERDICT r03 3d: reported next to the scaled verdict)
+    assert_close(x0t, g["inv_last.x0_t"], atol=1e-4 * _amp(b, 973), what="AFHQ inversion 973->999 x0_t")
+    x_edit, x_T = run_edit(m, x0, b, n_inv=40, n_gen=40, t_edit=444, learn_sigma=True, want_latent=True)
+    st_T, st_e = err_stats(x_T, g["x_T"]), err_stats(x_edit, g["x_edit"])
+    print("config3 free-running x_T", st_T)
+    print("config3 free-running x_edit", st_e)
+    assert st_T["max_abs"] <= 3e-4 * max(1.0, st_T["ref_absmax"]) and st_T["frac_outside"] <= 0.02
+    assert st_e["max_abs"] <= 3e-4 * max(1.0, st_e["ref_absmax"]) and st_e["frac_outside"] <= 0.02

@@ -142,3 +142,31 @@ def test_unet_forward_and_edit_small():
     eng = m._ready_engine(x4)
     with pytest.raises(_lib.AsyrpError, match="training step needs conv_math"):
         eng.train_forward(x4, 999, 749)
+
+
+def test_fast_mode_attention_off_the_1x1_kernel_batch_gt_1():
+    """attention at 8 x 8 puts the q|k|v projection on the 32x32x16 tile's split-plane epilogue (gemm1x1.hip
+    takes HW = 256 only); in the fast mode its lo planes are null, and for every image after the first the epilogue used to form
+    null + zo * stride before testing the pointer.  B = 3 in the fast mode: every row equals the image evaluated alone, bit for bit,
+    and the result stays within the mode's tolerance of the fp32 oracle."""
+    from oracle.ddpm import ddpm_forward
+    from oracle.weights import DDPMConfig
+    cfg = DDPMConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32)
+    sd = synthetic(cfg, 1, seed=21)
+    x = hash_normal("fm.attn8.x", (3, 3, 32, 32), seed=2)
+    t = torch.ones(3) * 701.0
+    with torch.no_grad():
+        want = ddpm_forward(sd, cfg, x, t, index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+    for math in ("f16", "f16x3"):
+        m = hip_model(cfg, sd, 1, conv_math=math, max_batch=4)
+        outs = m(x.cuda(), t.cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+        for i in range(3):
+            alone = m(x[i:i + 1].cuda().contiguous(), t[i:i + 1].cuda(), index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+            for a_, o_ in zip(alone, outs):
+                assert torch.equal(a_, o_[i:i + 1]), f"{math}: row {i} of the batch differs from the image alone"
+        for name, got, w_ in zip(("et", "et_mod", "delta_h", "middle_h"), outs, want):
+            if math == "f16":
+                r, mx = _rel_l2(got.cpu(), w_), float((got.cpu() - w_).abs().max())
+                assert r <= 5e-3 and mx <= 2e-2 * float(w_.abs().max()), f"fast mode {name}: rel L2 {r:.3e} max {mx:.3e}"
+            else:
+                assert_close(got, w_, what=f"f16x3 attention at 8x8 {name}")

@@ -199,3 +199,31 @@ def test_imagenet_adm_full_size_forward_vs_reference():
     for name, got in (("et", et), ("et_mod", em), ("delta_h", dh), ("middle_h", mh)):
         print(name, err_stats(got, g["fwd_dual." + name]))
         assert_close(got, g["fwd_dual." + name], what=name)
+
+
+def test_imagenet_adm_full_size_step_vs_reference():
+    """BASELINE config 5, one teacher-forced dual-decoder STEP at full size: learn_sigma split of the 6-channel
+    head (utils/diffusion_utils.py:47-51) + the DDIM update at the 1024-channel model, t = 700 -> 674, against the reference's own
+    denoising_step on i_DDPM('IMAGENET') (tests/golden/imagenet_adm_step.npz, make_golden.py run_imagenet_step)."""
+    import os
+    from asyrp_official_amd import i_DDPM
+    from conftest import GOLDEN
+    from oracle import sampler as osamp
+    if not os.path.exists(os.path.join(GOLDEN, "imagenet_adm_step.npz")):
+        pytest.skip("imagenet_adm_step.npz not generated (tests/golden/make_golden.py --only imagenet_step)")
+    g = load_golden("imagenet_adm_step.npz")
+    sd, x = imagenet_weights()
+    assert torch.equal(x[0, 0, 0, :8], g["probe.x"]) and torch.equal(sd["out.2.weight"].reshape(-1)[:8], g["probe.w"]), \
+        "CPU generator stream differs from the fixture's"
+    m = i_DDPM("IMAGENET", max_batch=1)
+    m.setattr_layers(1)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    b = osamp.beta_schedule()
+    m.set_schedule(b)
+    eng = m._ready_engine(x.cuda())
+    xn, x0t, dh, _ = eng.ddim_step(x.cuda(), 700, 674, apply_edit=True, index=0, hs_coeff=(1.0, 1.0), learn_sigma=True)
+    amp = max(1.0, float(osamp.alpha_bar(b)[700]) ** -0.5)
+    for name, got, atol in (("xt_next", xn, 1e-4), ("x0_t", x0t, 1e-4 * amp), ("delta_h", dh, 1e-4)):
+        print(name, err_stats(got, g["step." + name]))
+        assert_close(got, g["step." + name], atol=atol, what="ImageNet-ADM step " + name)

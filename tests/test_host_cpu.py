@@ -324,3 +324,25 @@ def test_bench_reports_counter_traffic_only_for_the_loaded_library_build(tmp_pat
     r = line()
     bench.paste_traffic(r, str(tmp_path / "missing.json"), str(lib), dt=8.0, steps=2)
     assert r["roofline"]["traffic"] is None and "traffic_note" not in r["roofline"]
+
+
+def test_bench_eight_rank_plumbing_dry_run_under_gloo():
+    """`python bench.py --gpus 8` end to end WITHOUT hardware: the real self-launch (torch.distributed.run, 8
+    ranks), rendezvous on 127.0.0.1, per-rank seeds, barrier + max-over-ranks timing and the one all-gather, with the engine replaced by
+    a stand-in per-image function on CPU tensors (--plumbing-dry-run), so that the first real 8-GPU run cannot fail on plumbing."""
+    import json
+    import subprocess
+    env = dict(os.environ, ASYRP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--plumbing-dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["world_size"] == 8 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["dry_run"] is True and res["value"] is None and res["scaling"] == "weak"
+    assert len(set(res["rank_seeds"])) == 8 and res["rank_seeds"] == [1234 + r_ for r_ in range(8)]
+    assert res["gathered_shape"] == [24, 3, 16, 16] and res["gathered_equals_unsharded"] is True
+    assert res["metric"].startswith("edited images/sec")

@@ -113,3 +113,37 @@ def test_shared_skip_partial_reproduces_conv1_for_both_decoder_inputs(c_h, c_s, 
         want = F.conv2d(a, w.double(), bias.double(), padding=1)
         got = F.conv2d(a[:, :c_clean], w[:, :c_clean].double(), bias.double(), padding=1) + part
         assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_vendored_class_schedule_tables_and_helpers_match_the_reference():
+    """The schedule tables / helper methods scripts read off the vendored GaussianDiffusion: same numbers as the
+    reference class builds (models/guided_diffusion/gaussian_diffusion.py:143-176, :205-231, :323-341) for the linear schedule."""
+    import sys
+    import numpy as np
+    import torch
+    ref_root = "/root/reference"
+    import os
+    if not os.path.isdir(ref_root):
+        import pytest
+        pytest.skip("reference not present")
+    sys.path.insert(0, ref_root)
+    try:
+        from models.guided_diffusion import gaussian_diffusion as rgd
+    finally:
+        sys.path.remove(ref_root)
+    from asyrp_official_amd.gaussian_diffusion import GaussianDiffusion
+    betas = np.linspace(1e-4, 0.02, 1000, dtype=np.float64)
+    ours = GaussianDiffusion(betas=betas, model_var_type="fixed_large")
+    ref = rgd.GaussianDiffusion(betas=betas, model_mean_type=rgd.ModelMeanType.EPSILON, model_var_type=rgd.ModelVarType.FIXED_LARGE,
+                                loss_type=rgd.LossType.MSE)
+    for name in ("alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                 "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                 "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_allclose(getattr(ours, name), getattr(ref, name), rtol=1e-12, atol=0, err_msg=name)
+    g = torch.Generator().manual_seed(3)
+    x0, xt, eps = (torch.randn((3, 3, 8, 8), generator=g) for _ in range(3))
+    t = torch.tensor([0, 500, 999])
+    torch.testing.assert_close(ours._predict_xstart_from_eps(xt, t, eps), ref._predict_xstart_from_eps(xt, t, eps), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ours.q_sample(x0, t, noise=eps), ref.q_sample(x0, t, noise=eps), rtol=1e-6, atol=1e-6)
+    for a_, b_ in zip(ours.q_posterior_mean_variance(x0, xt, t), ref.q_posterior_mean_variance(x0, xt, t)):
+        torch.testing.assert_close(a_, b_.float(), rtol=1e-6, atol=1e-7)
