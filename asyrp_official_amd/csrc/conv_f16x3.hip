@@ -1786,6 +1786,7 @@ constexpr int SKR_PIX = 8;    // pixels per reduce workgroup == pixels per stati
 
 int splitk_stat_blocks(int HW) { return (HW + SKR_PIX - 1) / SKR_PIX; }
 
+int splitk16_ranges();
 static int splitk_factor_impl(const GemmArgs& a, bool allow16) {
   if (a.math != MATH_F16X3 || !a.wpk || a.ks != 3 || a.stride != 1 || a.ups || a.s0 || a.rups || a.abl) return 1;
   // measured (profiles/r01_conv_microbench_kb8_splitk.txt, B=32): 1024->512 @8x8 179 -> 134 us; 512->512 @8x8 no gain (91 us
@@ -1796,7 +1797,7 @@ static int splitk_factor_impl(const GemmArgs& a, bool allow16) {
   // per CU with two waves per SIMD (matrix pipe 32 % busy, half of the wave cycles parked: profiles/rd3_pmc_families_*) -- a 2-way K
   // split fills the second slot (ASYRP_SPLITK16=0: off).  Blocks with a fused 1x1 shortcut keep the single-pass form (a.s0 above).
   if (small_class_tile(a)) return small_class_sk(a);
-  if (allow16 && splitk16(a)) return 2;
+  if (allow16 && splitk16(a)) return (a.Hout == 16) ? splitk16_ranges() : 2;
   if (a.Hout * a.Wout > 64 || a.Cin % 128 != 0 || !is_vec(a)) return 1;
   if (splitk_quad(a)) return 8;
   return a.Cin >= 1024 ? 8 : 1;
@@ -1807,19 +1808,25 @@ int splitk_factor_shared(const GemmArgs& a) { return splitk_factor_impl(a, false
 // a block's 1x1 shortcut runs as its own launch (and enters the reduce as the residual) instead of being fused: the quad form, and
 // the small class whenever the unfused conv splits K
 bool splitk_unfused(const GemmArgs& a) { return splitk_quad(a) || (small_class_tile(a) && small_class_sk(a) > 1); }
+// K ranges of the 16 x 16 layers: 2 on the 128-pixel form (two tiles per image), or (ASYRP_SPLITK16=4, experiment) 4 on the
+// 256-pixel main tile (one tile per image: twice the matrix work per weight slice and barrier)
+int splitk16_ranges() {
+  static const int n = [] { const char* e = getenv("ASYRP_SPLITK16"); return (e && e[0] == '4') ? 4 : 2; }();
+  return n;
+}
 bool splitk16(const GemmArgs& a) {
   static const bool on = [] { const char* e = getenv("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
   // ASYRP_SPLITK32=1 (experiment, off by default): the same for the 32 x 32 maps on the 256-pixel form (4 x Cout/128 workgroups per image)
   static const bool on32 = [] { const char* e = getenv("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
   const bool m16 = a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16, m32 = on32 && a.Hout == 32 && a.Wout == 32 && a.Hin == 32 && a.Win == 32;
   return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.poly && !a.s0 && !a.rups && (m16 || m32) &&
-         a.Cin >= 256 && (a.Cin % 64) == 0 && is_vec(a) && k32_preferred();
+         a.Cin >= 256 && (a.Cin % (m16 ? 32 * splitk16_ranges() : 64)) == 0 && is_vec(a) && k32_preferred();
 }
 // the tile a split launch runs on (a function of the layer shape only, like the factor)
 int splitk_tile(const GemmArgs& a) {
   if (const int t = small_class_tile(a)) return t;
   if (splitk_quad(a)) return XT_256x128K32Q;
-  if (splitk16(a)) return a.Hout == 32 ? XT_256x128K32 : XT_128x128K32;
+  if (splitk16(a)) return (a.Hout == 32 || splitk16_ranges() == 4) ? XT_256x128K32 : XT_128x128K32;
   return XT_64x64;
 }
 bool splitk_quad(const GemmArgs& a) {

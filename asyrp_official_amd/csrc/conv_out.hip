@@ -242,7 +242,9 @@ size_t conv_out_smem(int Cin, int TN) {
 }
 
 bool conv_out_two_tiles() {
-  static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return e && e[0] == '1'; }();
+  // (round 4: on by default -- with the loads two chunks ahead the two-N-tile form measured 55.5 vs 46.0 TFLOP/s on the AFHQ head,
+  //  +0.2 % on that edit, profiles/r04a_*; ASYRP_CONV_OUT6=0 puts the head back on the implicit-GEMM tile)
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return !(e && e[0] == '0'); }();
   return on;
 }
 bool conv_out_supported(const GemmArgs& a) {

@@ -254,21 +254,45 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
   }
   float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
   const bool want_stats = (p.stats != nullptr);
+  const bool full_tile = (n0 + BN <= Cout) && (m0 + BM <= HWo);
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int n = n0 + wn * 64 + tn * 16 + r16;
     const bool nok = n < Cout;
     const float add = nok ? ((p.bias ? p.bias[n] : 0.f) + (cadd ? cadd[n] : 0.f)) : 0.f;
     double s1 = 0.0, s2 = 0.0;
+    if (full_tile) {
+      // straight-line form for whole tiles (round 4): with the per-element bounds test hipcc put `s_waitcnt vmcnt(0)` in front of every
+      // residual load and store -- 64 serialized round trips per wave (the K32 kernel's epilogue had the same disease,
+      // profiles/r04b_*).  Here the sixteen residual values of a column block are requested together and the stores follow unwaited.
+      float rv[4][4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+      for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
-        if (nok && pix < HWo) {
-          const float v = (acc[tm][tn][r] * p.alpha + add) + (rz ? rz[(long long)pix * p.ldr + n] : 0.f);
+        for (int r = 0; r < 4; ++r) {
+          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
+          rv[tm][r] = rz ? rz[(long long)pix * p.ldr + n] : 0.f;
+        }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
+          const float v = (acc[tm][tn][r] * p.alpha + add) + rv[tm][r];
           outz[(long long)pix * p.ldo + n] = v;
           if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+        }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
+          if (nok && pix < HWo) {
+            const float v = (acc[tm][tn][r] * p.alpha + add) + (rz ? rz[(long long)pix * p.ldr + n] : 0.f);
+            outz[(long long)pix * p.ldo + n] = v;
+            if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+          }
         }
       }
     }
