@@ -51,5 +51,28 @@ int main() {
   }
   hipDeviceSynchronize();
   printf("bytes per launch: %zu\n", bytes);
+  // streaming rates with HIP events (round 4: what does this chip WRITE at? -- the yardstick for conv_in, whose launch is one
+  // 1.07 GB fp32 output tensor at B = 32): 1 GiB and 2 GiB passes, best of 5
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (size_t nb : {(size_t)1 << 30, bytes}) {
+    float best[3] = {1e9f, 1e9f, 1e9f};
+    for (int rep = 0; rep < 5; ++rep) {
+      for (int k = 0; k < 3; ++k) {
+        hipEventRecord(e0, 0);
+        if (k == 0) hipLaunchKernelGGL(read_f4, dim3(4096), dim3(256), 0, 0, reinterpret_cast<const float4*>(buf), sink, nb / 16);
+        if (k == 1) hipLaunchKernelGGL(write_f4, dim3(4096), dim3(256), 0, 0, reinterpret_cast<float4*>(buf), nb / 16);
+        if (k == 2) hipLaunchKernelGGL(write_row128, dim3(4096), dim3(256), 0, 0, buf, nb / 512);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best[k]) best[k] = ms;
+      }
+    }
+    printf("stream %4zu MiB: read_f4 %.3f TB/s  write_f4 %.3f TB/s  write_row128 %.3f TB/s\n", nb >> 20, nb / (best[0] * 1e-3) / 1e12,
+           nb / (best[1] * 1e-3) / 1e12, nb / (best[2] * 1e-3) / 1e12);
+  }
   return 0;
 }
