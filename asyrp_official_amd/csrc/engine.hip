@@ -3010,10 +3010,13 @@ static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int 
   if (upsample) { Ho *= 2; Wo *= 2; }
   if (stride == 2) { Ho /= 2; Wo /= 2; }
   std::vector<void*> tmp;
+  // ASYRP_BENCH_ZERO=1: activations and weights all zero (what does the same instruction stream run at when the matrix pipe's
+  // operands do not toggle?  profiling library only)
+  static const bool zero_data = [] { const char* e = getenv("ASYRP_BENCH_ZERO"); return e && e[0] == '1'; }();
   auto dalloc = [&](size_t nfloats, float** p, float scale, unsigned seed) -> int {
     HIPCHK(hipMalloc(p, std::max<size_t>(nfloats, 1) * sizeof(float)));
     tmp.push_back(*p);
-    hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, *p, (long long)nfloats, seed, scale);
+    hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, s, *p, (long long)nfloats, seed, zero_data ? 0.f : scale);
     return 0;
   };
   float *a0, *a1 = nullptr, *w, *wg, *bias, *yo, *rs = nullptr, *sc = nullptr, *sh = nullptr, *ca;
