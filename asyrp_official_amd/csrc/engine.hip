@@ -3044,18 +3044,22 @@ static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int 
   g.chan_add = ca; g.ld_chan_add = Cout;
   if (rs) { g.resid = rs; g.ldr = Cout; g.r_zo = (long long)Ho * Wo * Cout; }
   g.alpha = 1.f; g.out = yo; g.ldo = Cout; g.o_zo = (long long)Ho * Wo * Cout; g.ZI = 1; g.Z = B;
-  g.math = MATH_F32; g.tile = tile; g.abl = abl & ~64;
+  g.math = MATH_F32; g.tile = tile; g.abl = abl & 63;   // bit 6: GroupNorm partials, bit 7: stagger by arrival order, bits 8..: its delay in us
   if (abl & 64) {
     float* st;
     TRY(dalloc((size_t)B * 4 * ((Ho + 7) / 8) * ((Wo + 7) / 8) * Cout * 4, &st, 0.f, 14));   // >= [image][M block][Cout][2] doubles for any tile
     g.stats = reinterpret_cast<double*>(st);
   }
   unsigned long long* dbg = nullptr;
-  if (stamps_host && stamps_cap > 0) {
-    HIPCHK(hipMalloc(&dbg, (size_t)stamps_cap * 64));
+  size_t dbg_wgs = 0;
+  if ((stamps_host && stamps_cap > 0) || (abl & 128)) {
+    // [workgroup][8] stamps, then 2048 per-CU arrival counters (GemmArgs.stag == 3)
+    dbg_wgs = std::max<size_t>((size_t)std::max(stamps_cap, 0), (size_t)B * ((Ho + 15) / 16) * ((Wo + 15) / 16) * ((Cout + 127) / 128));
+    HIPCHK(hipMalloc(&dbg, dbg_wgs * 64 + 2048 * 8));
     tmp.push_back(dbg);
-    HIPCHK(hipMemsetAsync(dbg, 0, (size_t)stamps_cap * 64, s));
+    HIPCHK(hipMemsetAsync(dbg, 0, dbg_wgs * 64 + 2048 * 8, s));
     g.dbg = dbg;
+    if (abl & 128) { g.stag = 3; g.stag_ticks = ((abl >> 8) & 0xFFF) * 100; }
   }
   if (conv_math == ASYRP_MATH_F16X3 || conv_math == ASYRP_MATH_F16) {
     g.np = (conv_math == ASYRP_MATH_F16) ? 1 : 3;
@@ -3089,6 +3093,7 @@ static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int 
     TRY(dalloc((size_t)sk * B * Ho * Wo * Cout, &g.part, 0.f, 11));
   }
   auto once = [&]() -> hipError_t {
+    if (g.stag == 3 && hipMemsetAsync(dbg + dbg_wgs * 8, 0, 2048 * 8, s) != hipSuccess) return hipErrorUnknown;
     hipError_t e = launch_gemm(g, s);
     if (e == hipSuccess && sk > 1) e = launch_splitk_reduce(g, s);
     return e;
@@ -3106,7 +3111,7 @@ static int conv_bench_impl(int device, int B, int H, int W, int C0, int C1, int 
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (dbg && se == hipSuccess) (void)hipMemcpy(stamps_host, dbg, (size_t)stamps_cap * 64, hipMemcpyDeviceToHost);
+  if (dbg && stamps_host && stamps_cap > 0 && se == hipSuccess) (void)hipMemcpy(stamps_host, dbg, (size_t)stamps_cap * 64, hipMemcpyDeviceToHost);
   for (void* p : tmp) (void)hipFree(p);
   if (le != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench launch: ") + hipGetErrorString(le));
   if (se != hipSuccess) return fail(ASYRP_EHIP, std::string("conv bench sync: ") + hipGetErrorString(se));

@@ -5,6 +5,7 @@ usage: scripts/k32_phases.py [B]"""
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -65,7 +66,7 @@ def report(H, C0, C1, Cout, **kw):
           f"that CU) mean {gaps.mean():.2f} us p10 {np.percentile(gaps, 10):.2f} p50 {np.percentile(gaps, 50):.2f} p90 {np.percentile(gaps, 90):.2f}")
     first = us(np.sort(s[:, 0]) - t0)
     print(f"    workgroup start times (us) at quantiles 1/6/12/50 %: " + " ".join(f"{first[int(q * (len(first) - 1))]:.1f}" for q in (0.01, 0.06, 0.12, 0.5)))
-    return ms
+    return ms, st
 
 
 def run(H, C0, C1, Cout, tile=TILE, abl=0, iters=8, res=0):
@@ -74,8 +75,104 @@ def run(H, C0, C1, Cout, tile=TILE, abl=0, iters=8, res=0):
     return ms.value
 
 
+def cu_key(st):
+    hw = st[:, 5]
+    xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
+    hwid = (hw & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    return (((xcc * 8 + ((hwid >> 13) & 0x7)) * 2 + ((hwid >> 12) & 0x1)) * 16 + ((hwid >> 8) & 0xF)), hwid & 0xF, (hwid >> 4) & 3
+
+
+def overlap_report(st):
+    """How much of a workgroup's K loop runs beside its CU partner's K loop (stamps 1..2), beside the partner's other phases, and
+    the offset between the starts of the two workgroups resident on a CU (0 = lockstep, half a life = fully staggered)."""
+    s = st.astype(np.int64)
+    key, _, _ = cu_key(st)
+    both, offs = [], []
+    for k in np.unique(key):
+        idx = np.where(key == k)[0]
+        idx = idx[np.argsort(s[idx, 0])]
+        iv = [(s[i, 1], s[i, 2]) for i in idx]
+        for n, i in enumerate(idx):
+            a, b = iv[n]
+            cov = 0
+            for m in range(max(0, n - 3), min(len(idx), n + 4)):
+                if m != n:
+                    cov += max(0, min(b, iv[m][1]) - max(a, iv[m][0]))
+            both.append(cov / max(1, b - a))
+            if n >= 1:
+                life = max(1, s[i, 6] - s[i, 0])
+                offs.append(((s[i, 0] - s[idx[n - 1], 0]) % life) / life)
+    both, offs = np.array(both), np.array(offs)
+    print(f"    K-loop time spent beside the partner's K loop: mean {both.mean():.2f} p10 {np.percentile(both, 10):.2f} p90 {np.percentile(both, 90):.2f}; "
+          f"start offset to the previous workgroup on the CU / own life: p10 {np.percentile(offs, 10):.2f} p50 {np.percentile(offs, 50):.2f} p90 {np.percentile(offs, 90):.2f}")
+
+
+def dispatch_map(H=256, C0=128, C1=0, Cout=128):
+    """Which linear workgroup ids share a CU in the first dispatch round, and which wave slots (HW_ID.WAVE_ID) they got."""
+    ms, st = stamps(H, C0, C1, Cout, abl=32 | 64 | 128)     # stagger mode 3 with 0 us: records the arrival order in slot 7
+    key, wave_id, simd = cu_key(st)
+    arr = st[:, 7].astype(np.int64)
+    n = min(len(st), 768)
+    first = {}
+    for i in range(n):
+        first.setdefault(int(key[i]), []).append((i, int(arr[i]), int(wave_id[i]), int(simd[i])))
+    pairs = [v for v in first.values() if len(v) >= 2]
+    d = np.array([v[1][0] - v[0][0] for v in pairs])
+    print(f"-- dispatch map, first {n} linear ids: {len(first)} CUs; linear-id distance between the first two workgroups of a CU: "
+          f"min {d.min()} p50 {int(np.median(d))} max {d.max()}; examples {[v[:3] for v in list(first.values())[:4]]}")
+    lt512 = [(a, w) for v in first.values() for (i, a, w, _) in v if i < 512]
+    a0 = [w for a, w in lt512 if a == 0]
+    a1 = [w for a, w in lt512 if a == 1]
+    print(f"   ids < 512: arrival 0 -> wave ids {sorted(set(a0))}, arrival 1 -> wave ids {sorted(set(a1))}, arrivals >= 2: {sum(1 for a, w in lt512 if a >= 2)}; "
+          f"ids in [256, 512) with arrival 1: {sum(1 for v in first.values() for (i, a, w, _) in v if 256 <= i < 512 and a == 1)} of 256")
+
+
+def timed_loop(fn, seconds=2.5):
+    from gpuclk import Sampler
+    vals = []
+    with Sampler() as sm:
+        t0 = time.time()
+        while time.time() - t0 < seconds:
+            vals.append(fn())
+    return float(np.median(vals)), sm
+
+
 if __name__ == "__main__":
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     what = sys.argv[2] if len(sys.argv) > 2 else "all"
+    if what == "map":
+        dispatch_map()
+        sys.exit(0)
+    if what == "stagger":      # ablation instantiation with stamps: second workgroup of every CU delayed once (by arrival order)
+        for kw in ({}, {"abl": 32}, {"res": 1}):
+            for us_ in (0, 30, 45, 60):
+                k = dict(kw)
+                base = k.pop("abl", 32 | 64)
+                print(f"## stagger {us_} us", flush=True)
+                ms, st = report(256, 128, 0, 128, abl=base | ((128 | (us_ << 8)) if us_ else 0), **k)
+                overlap_report(st)
+        for us_ in (0, 85):
+            print(f"## stagger {us_} us", flush=True)
+            ms, st = report(256, 128, 128, 128, abl=32 | 64 | ((128 | (us_ << 8)) if us_ else 0))
+            overlap_report(st)
+        sys.exit(0)
+    if what == "clk":          # sclk / power per variant of the same instantiation (VERDICT r04: is the 2.19 vs 2.48 us/step a clock effect?)
+        for name, kw in (("stats", dict(abl=32 | 64)), ("no stats", dict(abl=32)), ("stats + residual", dict(abl=32 | 64, res=1)),
+                         ("product kernel, stats", dict(abl=64)), ("product kernel, stats + residual", dict(abl=64, res=1))):
+            ms, sm = timed_loop(lambda: run(256, 128, 0, 128, iters=20, **kw))
+            print(f"   128->128 @256 {name:34s}: {ms * 1e3:8.1f} us per launch {2.0 * B * 65536 * 128 * 128 * 9 / (ms * 1e-3) / 1e12:6.1f} TFLOP/s; {sm.summary()}", flush=True)
+        sys.exit(0)
+    if what == "prod":         # product kernel under the process's ASYRP_STAGGER* environment
+        print(f"-- product kernel, ASYRP_STAGGER={os.environ.get('ASYRP_STAGGER', '0')} US={os.environ.get('ASYRP_STAGGER_US', '-')} ROUNDS={os.environ.get('ASYRP_STAGGER_ROUNDS', '-')}")
+        for name, a, kw in (("128->128 @256 stats", (256, 128, 0, 128), dict(abl=64)), ("128->128 @256 plain", (256, 128, 0, 128), {}),
+                            ("128->128 @256 stats+res", (256, 128, 0, 128), dict(abl=64, res=1)), ("256->128 @256 stats", (256, 128, 128, 128), dict(abl=64)),
+                            ("128->128 @128 stats+res", (128, 128, 0, 128), dict(abl=64, res=1)), ("256->256 @64 stats", (64, 256, 0, 256), dict(abl=64)),
+                            ("512->256 @64 stats", (64, 256, 256, 256), dict(abl=64))):
+            r = sorted(run(*a, iters=12, **kw) for _ in range(5))[2]
+            fl = 2.0 * B * a[0] * a[0] * a[3] * (a[1] + a[2]) * 9
+            print(f"   {name:28s}: {r * 1e3:8.1f} us {fl / (r * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
+        sys.exit(0)
     if what in ("all", "sweep"):
         print(f"-- K sweep at a fixed grid (Cout = 128 @256^2, B={B}, product kernel): time = a + b * steps")
         xs, ys = [], []

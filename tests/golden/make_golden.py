@@ -15,6 +15,8 @@ and records reference outputs as .npz fixtures next to this script:
   config4_church_gothic.npz    BASELINE config 4's model: LSUN-church DDPM + the shipped `church_gothic` DeltaBlock, t_edit=370,
                    three teacher-forced steps at full size
   imagenet_adm.npz BASELINE config 5's model at full size: i_DDPM('IMAGENET'), B=1, one dual-decoder forward
+  config4_church_full.npz / imagenet_adm_traj.npz / iddpm_afhq_b2.npz   (round 5) config 4 end to end (x_T, x_edit of 39 + 40 steps),
+                   a free-running 3 + 4-step trajectory of config 5's model, an iDDPM batch of two different images
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; ~1 min on 8 cores)
 """
@@ -293,7 +295,7 @@ def config1_state_dict(tame=1.0):
     (checkpoint/smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth["0"], loaded as diffusion_latent.py:674-676 does)."""
     sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=1234)
     ck = torch.load(os.path.join(REF, "checkpoint", "smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth"), map_location="cpu",
-                    weights_only=False)["0"]
+                    weights_only=True)["0"]
     for k, v in ck.items():
         sd["layer_0." + k] = v.float().clone()
     if tame != 1.0:   # see run_config1
@@ -411,7 +413,7 @@ def run_config3(out):
     torch.set_num_threads(os.cpu_count())
     sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
     ck = torch.load(os.path.join(REF, "checkpoint", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"), map_location="cpu",
-                    weights_only=False)["0"]
+                    weights_only=True)["0"]
     for k, v in ck.items():
         sd["layer_0." + k] = v.float().clone()
     m = ref_iddpm(AFHQ, sd, 1)
@@ -587,7 +589,7 @@ def run_config4(out):
     torch.set_num_threads(os.cpu_count())
     sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=4004)
     ck = torch.load(os.path.join(REF, "checkpoint", "church_gothic_LC_church_outdoor_t999_ninv40_ngen40_0.pth"),
-                    map_location="cpu", weights_only=False)["0"]
+                    map_location="cpu", weights_only=True)["0"]
     for k, v in ck.items():
         sd["layer_0." + k] = v.float().clone()
     m = ref_model(CELEBA, sd, n_delta=1)
@@ -620,7 +622,7 @@ def run_config3_full(out):
     torch.set_num_threads(os.cpu_count())
     sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
     ck = torch.load(os.path.join(REF, "checkpoint", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"), map_location="cpu",
-                    weights_only=False)["0"]
+                    weights_only=True)["0"]
     for k, v in ck.items():
         sd["layer_0." + k] = v.float().clone()
     m = ref_iddpm(AFHQ, sd, 1)
@@ -711,12 +713,107 @@ def run_config1_b2(out):
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
+def run_config4_full(out):
+    """BASELINE config 4's model END TO END through the REFERENCE: the LSUN-church DDPM + the SHIPPED `church_gothic`
+    DeltaBlock, B=1, a seeded image -> 39 DDIM inversion steps (diffusion_latent.py:1034-1045) -> x_T -> 40 Asyrp steps with t_edit=370
+    (utils/t_edit_dic.py:3; diffusion_latent.py:503-520).  Stored: x_T and x_edit only (the DeltaBlock is in config4_church_gothic.npz,
+    the image and the base weights are hash-generated)."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd = synthetic_state_dict(ddpm_param_shapes(CELEBA, n_delta=1), seed=4004)
+    ck = torch.load(os.path.join(REF, "checkpoint", "church_gothic_LC_church_outdoor_t999_ninv40_ngen40_0.pth"),
+                    map_location="cpu", weights_only=True)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    m = ref_model(CELEBA, sd, n_delta=1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim")
+    seq, seq_next = _seq40()
+    one = torch.ones(1)
+    g = {}
+    with torch.no_grad():
+        x = hash_uniform("config4.x0", (1, 3, 256, 256), seed=4004)
+        for i, j in zip(seq_next[1:], seq[1:]):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0, **kw)
+        g["x_T"] = x.clone()
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=370, hs_coeff=(1.0, 1.0), **kw)
+        g["x_edit"] = x.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_imagenet_traj(out):
+    """BASELINE config 5, a short FREE-RUNNING trajectory through the REFERENCE: i_DDPM('IMAGENET') (553.8 M
+    parameters), B=1, n_inv = n_gen = 4 on the reference's own time grid (np.linspace(0, 1, 4) * 999 = 0, 333, 666, 999): 3 DDIM
+    inversion steps with learn_sigma, then 4 Asyrp steps with index=0, t_edit=500 (two dual-decoder steps, two single-decoder steps,
+    the last one to t_next = -1).  Stored: x_T, x_edit and the delta_h of the first edited step."""
+    from models.improved_ddpm.script_util import i_DDPM
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    torch.set_num_threads(os.cpu_count())
+    sd, _ = imagenet_state_dict()
+    m = i_DDPM("IMAGENET")
+    m.setattr_layers(1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval()
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", learn_sigma=True)
+    seq = [int(s + 1e-6) for s in list(np.linspace(0, 1, 4) * 999)]      # diffusion_latent.py:955-957 with n_inv = 4
+    seq_next = [-1] + seq[:-1]
+    one = torch.ones(1)
+    g = {"seq": torch.tensor(seq, dtype=torch.float32)}
+    with torch.no_grad():
+        x = hash_uniform("imagenet.traj.x0", (1, 3, 256, 256), seed=77)
+        for i, j in zip(seq_next[1:], seq[1:]):
+            x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0, **kw)
+        g["x_T"] = x.clone()
+        first = True
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            x, _, dh, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0), **kw)
+            if first:
+                g["gen999.delta_h"], g["gen999.xt_next"] = dh.clone(), x.clone()
+                first = False
+        g["x_edit"] = x.clone()
+    g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
+def run_afhq_b2(out):
+    """An iDDPM BATCH pinned to the reference directly (models/improved_ddpm/unet.py:676-752): AFHQ-Dog iDDPM + the
+    shipped `dog_happy` DeltaBlock, B = 2 with two DIFFERENT images, teacher-forced steps executed by the REFERENCE on the whole batch:
+    an inversion step with learn_sigma and an edited (dual-decoder) generation step."""
+    from utils.diffusion_utils import denoising_step, get_beta_schedule
+    from oracle.iddpm import AFHQ, iddpm_param_shapes
+    torch.set_num_threads(os.cpu_count())
+    sd = synthetic_state_dict(iddpm_param_shapes(AFHQ, n_delta=1), seed=4321)
+    ck = torch.load(os.path.join(REF, "checkpoint", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"), map_location="cpu",
+                    weights_only=True)["0"]
+    for k, v in ck.items():
+        sd["layer_0." + k] = v.float().clone()
+    m = ref_iddpm(AFHQ, sd, 1)
+    betas = torch.from_numpy(get_beta_schedule(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    kw = dict(models=m, logvars=np.zeros(1000), b=betas, sampling_type="ddim", eta=0.0, learn_sigma=True)
+    two = torch.ones(2)
+    g = {}
+    with torch.no_grad():
+        x0 = torch.cat([hash_uniform("afhqb2.x0a", (1, 3, 256, 256), seed=21), hash_uniform("afhqb2.x0b", (1, 3, 256, 256), seed=22)])
+        xn, _, _, _ = denoising_step(x0, t=two * 0, t_next=two * 25, **kw)
+        g["inv0.xt_next"] = xn.clone()
+        xm = torch.cat([hash_normal("afhqb2.xma", (1, 3, 256, 256), seed=23), hash_normal("afhqb2.xmb", (1, 3, 256, 256), seed=24)])
+        xn, _, dh, _ = denoising_step(xm, t=two * 768, t_next=two * 742, index=0, t_edit=444, hs_coeff=(1.0, 1.0), **kw)
+        g["gen768.xt_next"], g["gen768.delta_h"] = xn.clone(), dh.clone()
+    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
+
+
 def run_checkpoint_keys(out):
     """Key names / shapes of the shipped DeltaBlock checkpoints (one per UNet family) -> delta_checkpoint_keys.json."""
     import json
     res = {}
     for f in ("smiling_LC_CelebA_HQ_t999_ninv40_ngen40_0.pth", "dog_happy_LC_dog_t999_ninv40_ngen40_0.pth"):
-        sd = torch.load(os.path.join(REF, "checkpoint", f), map_location="cpu", weights_only=False)["0"]
+        sd = torch.load(os.path.join(REF, "checkpoint", f), map_location="cpu", weights_only=True)["0"]
         res[f] = {k: list(v.shape) for k, v in sd.items()}
     json.dump(res, open(out, "w"), indent=1)
     print("wrote", out)
@@ -724,7 +821,7 @@ def run_checkpoint_keys(out):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers", "imagenet", "config4", "config3_full", "imagenet_step", "config1_b2"], default=None)
+    ap.add_argument("--only", choices=["small", "celeba", "keys", "iddpm_small", "iddpm_small2", "afhq", "slerp", "config1", "config1_tame", "config3", "train", "samplers", "imagenet", "config4", "config3_full", "imagenet_step", "config1_b2", "config4_full", "imagenet_traj", "afhq_b2"], default=None)
     a = ap.parse_args()
     if a.only in (None, "keys"):
         run_checkpoint_keys(os.path.join(HERE, "delta_checkpoint_keys.json"))
@@ -760,3 +857,9 @@ if __name__ == "__main__":
         run_imagenet_step(os.path.join(HERE, "imagenet_adm_step.npz"))
     if a.only in (None, "config3_full"):
         run_config3_full(os.path.join(HERE, "config3_afhq_full.npz"))
+    if a.only in (None, "config4_full"):
+        run_config4_full(os.path.join(HERE, "config4_church_full.npz"))
+    if a.only in (None, "afhq_b2"):
+        run_afhq_b2(os.path.join(HERE, "iddpm_afhq_b2.npz"))
+    if a.only in (None, "imagenet_traj"):
+        run_imagenet_traj(os.path.join(HERE, "imagenet_adm_traj.npz"))
