@@ -918,36 +918,26 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   constexpr int WCH = BN / WN;                 // output channels per wave
   constexpr int FR = T::FR, STRIDE = T::STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // ---- stagger (GemmArgs.stag): all resident workgroups of a launch start together, so the two workgroups of a CU run their
-  // prologue / epilogue / statistics phases at the same time and the matrix pipe idles through them; delaying the second workgroup
-  // of every CU once, in the first dispatch round, puts one's epilogue under the other's K loop for the rest of the launch
-  // (both have the same life time, so the offset persists).  Wave-uniform; timing only.
-  if (p.stag) {
+  // ---- stagger experiment (profiling library only, GemmArgs.stag == 3; round 5): the second workgroup to arrive on a CU waits
+  // stag_ticks once.  Measured (profiles/r05a_k32_stagger_stamps.txt): the two workgroups of a CU already run half a life apart
+  // without it (start offset / life: p10 0.46, p50 0.50, p90 0.54 -- the first dispatch round starts in lockstep and the pair drifts
+  // into anti-phase by itself), and forcing 30 / 45 / 60 us changes the launch time by +-1 %: there is nothing to collect here.
+  if (ABL && p.stag == 3 && p.dbg) {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    bool late = false;
-    if (p.stag == 1) {
-      late = (lin >= 256 && lin < 512);
-    } else if (p.stag == 2) {
-      unsigned hw;
+    int* flag = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) {   // arrival order on this CU (counters behind the stamps, zeroed by the bench hook before every launch)
+      unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      late = (lin < 512 && (hw & 0xF) >= 2);
-    } else if (ABL && p.stag == 3 && p.dbg) {
-      // arrival order on this CU (counters behind the stamps, zeroed by the bench hook before every launch)
-      int* flag = reinterpret_cast<int*>(smem);
-      if (threadIdx.x == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned key = ((((xcc & 0xF) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)) & 2047;
-        const size_t nwg = (size_t)gridDim.x * gridDim.y * gridDim.z;
-        const unsigned long long arr = atomicAdd(p.dbg + nwg * 8 + key, 1ULL);
-        p.dbg[(size_t)lin * 8 + 7] = arr;
-        *flag = (arr == 1);
-      }
-      __syncthreads();
-      late = (*flag != 0);
-      __syncthreads();
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      const unsigned key = ((((xcc & 0xF) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)) & 2047;
+      const size_t nwg = (size_t)gridDim.x * gridDim.y * gridDim.z;
+      const unsigned long long arr = atomicAdd(p.dbg + nwg * 8 + key, 1ULL);
+      p.dbg[(size_t)lin * 8 + 7] = arr;
+      *flag = (arr == 1);
     }
+    __syncthreads();
+    const bool late = (*flag != 0);
+    __syncthreads();
     if (late) {
       const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)p.stag_ticks;
       while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(16);
@@ -1539,13 +1529,6 @@ static hipError_t launch_x(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// A/B switches of the workgroup stagger (round 5): ASYRP_STAGGER = 0 (off) | 1 (by linear id) | 2 (by wave slot),
-// ASYRP_STAGGER_US = fixed delay instead of the K-step rule, ASYRP_STAGGER_ROUNDS = minimum dispatch rounds of a launch
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static int stagger_mode() { static const int v = env_int("ASYRP_STAGGER", 0); return v; }
-static int stagger_us() { static const int v = env_int("ASYRP_STAGGER_US", 0); return v; }
-static int stagger_min_rounds() { static const int v = env_int("ASYRP_STAGGER_ROUNDS", 4); return v; }
-
 using K32Main = K32Cfg<8, 2>;
 using K32Half = K32Cfg<8, 4>;
 using K32Img8 = K32Cfg<8, 8, 8>;
@@ -1560,17 +1543,6 @@ static hipError_t launch_k32(const GemmArgs& a, hipStream_t s) {
   dim3 grid(gx, gy, T::QUAD ? (a.Z + 3) / 4 : a.Z * (T::KS == 2 ? 4 : 1)), block(T::NT);
   GemmArgs ax = a;
   ax.xmap = (xcd_map_enabled() && gx >= 16 && (gx & 7) == 0 && (gy * (long long)gx) % 8 == 0) ? 1 : 0;
-  if (!ABL) {
-    // stagger of the CU's two workgroups (see the kernel): main tile, launches of at least stagger_min_rounds() dispatch rounds;
-    // the late workgroups wait about half a tile life (K steps x ~1.25 us + the fixed phases)
-    ax.stag = 0;
-    const long long wgs = (long long)gx * gy * grid.z;
-    if (stagger_mode() && T::BM == 256 && !T::QUAD && !SPK && wgs >= 512LL * stagger_min_rounds()) {
-      const int steps = (a.Cin / XKC) * T::NTAPS / 2 + (SC ? a.Cin2 / (2 * XKC) : 0);
-      ax.stag = stagger_mode();
-      ax.stag_ticks = stagger_us() > 0 ? stagger_us() * 100 : steps * 125 + 700;
-    }
-  }
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);

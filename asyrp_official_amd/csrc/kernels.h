@@ -62,11 +62,8 @@ struct GemmArgs {
   int nz;                         // nominal batch of the engine's batch class (tile / split-K rules are priced at it, never at Z); 0 = 32
   int np;                         // f16x3 family: matrix products per term: 0 / 3 = two-term split (fp32-equivalent), 1 = single f16 product
   unsigned long long* dbg;        // profiling library only: phase stamps [workgroup][8] of the K32 ablation instantiation (null in the product)
-  // stagger of the two resident workgroups of a CU (K32 main tile, round 5; set by launch_k32): the workgroups of the first dispatch
-  // round that are the SECOND on their CU start stag_ticks (100 MHz) late, once, so that the pair's non-matrix phases (prologue,
-  // epilogue, statistics) do not coincide for the rest of the launch.  1 = by linear workgroup id ([ncu, 2 ncu)), 2 = by the wave
-  // slot in HW_ID, 3 = by arrival order on the CU (profiling library only: counters behind the stamps in dbg).  Timing only:
-  // results do not depend on it.
+  // profiling library only (K32 ablation instantiation): stag == 3 delays the second workgroup to arrive on a CU by stag_ticks
+  // (100 MHz) once; the arrival counters sit behind the stamps in dbg.  0 in the product.
   int stag, stag_ticks;
 };
 

@@ -8,60 +8,68 @@ import time
 
 
 def _paths():
-    best = None
+    """One entry per card that has a hwmon directory (a 1-GPU box may still list every card of the node in sysfs)."""
+    cards = []
     for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
         hw = sorted(glob.glob(dev + "/hwmon/hwmon*"))
         if not hw:
             continue
         h = hw[0]
-        cand = {"freq": h + "/freq1_input", "pavg": h + "/power1_average", "pin": h + "/power1_input", "dpm": dev + "/pp_dpm_sclk"}
-        try:
-            open(cand["freq"]).read()
-        except OSError:
-            cand["freq"] = None
-        best = best or cand
-        if cand["freq"]:
-            return cand
-    return best
+        cards.append({"freq": h + "/freq1_input", "pavg": h + "/power1_average", "pin": h + "/power1_input", "dpm": dev + "/pp_dpm_sclk"})
+    return cards
 
 
 _P = None
 
 
-def read():
-    """-> (sclk MHz or None, watts or None)"""
-    global _P
-    if _P is None:
-        _P = _paths() or {}
+def _read_card(c):
     mhz = watts = None
     try:
-        if _P.get("freq"):
-            mhz = int(open(_P["freq"]).read()) / 1e6
-        elif _P.get("dpm"):
-            for line in open(_P["dpm"]).read().splitlines():
+        mhz = int(open(c["freq"]).read()) / 1e6
+    except (OSError, ValueError):
+        try:
+            for line in open(c["dpm"]).read().splitlines():
                 if "*" in line:
                     mhz = float(re.search(r"(\d+)\s*Mhz", line, re.I).group(1))
-    except (OSError, ValueError, AttributeError):
-        pass
+        except (OSError, ValueError, AttributeError):
+            pass
     for k in ("pavg", "pin"):
         try:
-            if _P.get(k):
-                watts = int(open(_P[k]).read()) / 1e6
-                break
+            watts = int(open(c[k]).read()) / 1e6
+            break
         except (OSError, ValueError):
             pass
+    return mhz, watts
+
+
+def read():
+    """-> (sclk MHz or None, watts or None) of the BUSIEST card (highest socket power): the one this process is running on"""
+    global _P
+    if _P is None:
+        _P = _paths()
+    best = (None, None)
+    for c in _P:
+        mhz, watts = _read_card(c)
+        if watts is not None and (best[1] is None or watts > best[1]):
+            best = (mhz, watts)
+    mhz, watts = best
     if mhz is None or watts is None:
         try:
             out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+            rows = {}
             for line in out.splitlines():
-                if "GPU[0]" not in line:
+                m0 = re.match(r"GPU\[(\d+)\]", line)
+                if not m0:
                     continue
+                r = rows.setdefault(int(m0.group(1)), [None, None])
                 m = re.search(r"sclk clock level.*\((\d+)Mhz\)", line)
-                if m and mhz is None:
-                    mhz = float(m.group(1))
+                if m:
+                    r[0] = float(m.group(1))
                 m = re.search(r"Power \(W\):\s*([\d.]+)", line)
-                if m and watts is None:
-                    watts = float(m.group(1))
+                if m:
+                    r[1] = float(m.group(1))
+            if rows:
+                mhz, watts = max(rows.values(), key=lambda r: r[1] or 0.0)
         except (OSError, subprocess.SubprocessError):
             pass
     return mhz, watts
@@ -104,5 +112,6 @@ class Sampler:
 
 
 if __name__ == "__main__":
-    print(_paths())
+    cs = _paths()
+    print(len(cs), "cards with hwmon;", [(_read_card(c)) for c in cs])
     print(read())

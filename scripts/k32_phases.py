@@ -163,8 +163,8 @@ if __name__ == "__main__":
             ms, sm = timed_loop(lambda: run(256, 128, 0, 128, iters=20, **kw))
             print(f"   128->128 @256 {name:34s}: {ms * 1e3:8.1f} us per launch {2.0 * B * 65536 * 128 * 128 * 9 / (ms * 1e-3) / 1e12:6.1f} TFLOP/s; {sm.summary()}", flush=True)
         sys.exit(0)
-    if what == "prod":         # product kernel under the process's ASYRP_STAGGER* environment
-        print(f"-- product kernel, ASYRP_STAGGER={os.environ.get('ASYRP_STAGGER', '0')} US={os.environ.get('ASYRP_STAGGER_US', '-')} ROUNDS={os.environ.get('ASYRP_STAGGER_ROUNDS', '-')}")
+    if what == "prod":         # product kernel, median of 5 x 12 launches per shape (same-box A/B lines across library builds / environments)
+        print("-- product kernel")
         for name, a, kw in (("128->128 @256 stats", (256, 128, 0, 128), dict(abl=64)), ("128->128 @256 plain", (256, 128, 0, 128), {}),
                             ("128->128 @256 stats+res", (256, 128, 0, 128), dict(abl=64, res=1)), ("256->128 @256 stats", (256, 128, 128, 128), dict(abl=64)),
                             ("128->128 @128 stats+res", (128, 128, 0, 128), dict(abl=64, res=1)), ("256->256 @64 stats", (64, 256, 0, 256), dict(abl=64)),
