@@ -46,6 +46,8 @@ class HipUNet(nn.Module):
         # batch class of the engine (include/asyrp.h asyrp_config.nominal_batch): 0 = kernels priced at 32 images per GPU (default),
         # 1 / 2 = the small class for single-image serving.  Fixed per engine; results of two classes agree to fp32 rounding.
         self.nominal_batch = int(nominal_batch)
+        if self.nominal_batch not in (0, 1, 2, 32):
+            raise ValueError(f"nominal_batch must be 0 (= 32, the default class), 1, 2 (the small class) or 32, got {nominal_batch}")
         # "f16x3" (3 x f16 MFMA, fp32-equivalent, default), "f32" (fp32 MFMA), or the fast mode "f16" (ONE f16 MFMA per product:
         # not fp32-equivalent, reported separately with its own error; include/asyrp.h enum asyrp_conv_math)
         self.conv_math = conv_math
@@ -91,6 +93,15 @@ class HipUNet(nn.Module):
         if self._engine is not None:
             self._engine.close()
         self._engine, self._engine_sig, self._uploaded = None, None, {}
+
+    def _replicate_for_data_parallel(self):
+        """torch.nn.DataParallel over MORE than one device (diffusion_latent.py:591 on a multi-GPU host) replicates the module per
+        device with shallow copies: every replica would drive ONE engine handle, bound to one GPU, from its own thread.  Fail loudly;
+        the supported multi-GPU form is one process per GPU (sampler.run_edit_sharded).  With a single device
+        DataParallel calls the module directly and never gets here."""
+        raise AsyrpDeviceError(f"{type(self).__name__} cannot be replicated by torch.nn.DataParallel across several GPUs: the HIP engine "
+                               "is bound to one device. Launch one process per GPU (torch.distributed.run) and use "
+                               "asyrp_official_amd.run_edit_sharded instead.")
 
     def set_schedule(self, betas):
         """Hand the beta schedule (the `b` the reference passes to denoising_step) to the engine."""

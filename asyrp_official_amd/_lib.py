@@ -27,7 +27,7 @@ class AsyrpConfig(C.Structure):
 
 
 _P, _F, _I = C.c_void_p, C.c_float, C.c_int
-ABI_VERSION = 7   # include/asyrp.h ASYRP_ABI_VERSION
+ABI_VERSION = 8   # include/asyrp.h ASYRP_ABI_VERSION
 
 _SIGS = {
     "asyrp_abi_version": (C.c_int, []),

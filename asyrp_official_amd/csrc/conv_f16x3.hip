@@ -1359,7 +1359,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     float add4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) add4[j] = nok ? ((has_b ? p.bias[nq + j] : 0.f) + (has_c ? cadd[nq + j] : 0.f)) : 0.f;
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     // item i of row block tm: block row m = prow + i * RSTEP -> output pixel, residual pixel, inside the image?
     auto geom = [&](int tm, int i, int& pixel, int& rpix) -> bool {
       const int m = prow + i * RSTEP;
@@ -1374,11 +1373,19 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       v.z = (a.z + add4[2]) + r.z;
       v.w = (a.w + add4[3]) + r.w;
     };
+    // GroupNorm partials (round 5): the 4 x NV values of a channel that a lane stores are summed in fp32 (packed v_pk_add_f32 /
+    // v_pk_fma_f32, fixed order) and join the double-precision chain (lanes -> wave rows -> tiles -> gn_finalize2) as ONE pair of
+    // sums per lane and channel.  Before, every value was converted, squared and added in f64 (half-rate instructions: 2.8 % of a
+    // main-tile launch, profiles/r05a_k32_product_kernel_*, and 16 live registers).  <= 15 roundings of 2^-24 per partial sum, with
+    // random signs over the >= 64 partials of a group: 1e-8-class relative error on a group's moments, below the reference's own
+    // fp32 moments.  Deterministic and batch-invariant as before (same values, same order).
+    f2 q1a = {0.f, 0.f}, q1b = {0.f, 0.f}, q2a = {0.f, 0.f}, q2b = {0.f, 0.f};
     auto stat4 = [&](const float4& v) {
-      s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
-      s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
-      s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
-      s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+      const f2 a = {v.x, v.y}, b = {v.z, v.w};
+      q1a += a;
+      q1b += b;
+      q2a = __builtin_elementwise_fma(a, a, q2a);
+      q2b = __builtin_elementwise_fma(b, b, q2b);
     };
     if (full) {
       // straight-line code (no per-element predicate, so hipcc counts vmcnt instead of draining it): the residual rows of block
@@ -1442,6 +1449,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
     K32_STAMP(3);
     if (want_stats) {   // fixed-order reduction over the lanes that hold the same channel quad, then over the wave rows below
+      double s1[4] = {(double)q1a[0], (double)q1a[1], (double)q1b[0], (double)q1b[1]};
+      double s2[4] = {(double)q2a[0], (double)q2a[1], (double)q2b[0], (double)q2b[1]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1608,9 +1617,16 @@ constexpr int NOMINAL_Z = 32;   // BASELINE.json configs[1]: 32 images per GPU
 static int nominal_z(const GemmArgs& a) { return a.nz > 0 ? a.nz : NOMINAL_Z; }
 static bool is_vec(const GemmArgs& a);
 static bool k32_preferred();
+// what k32_epilogue_ok will say about a launch of this layer once the split-K fields (sk, part) are filled in: the part buffer is
+// the engine's own 256-byte-aligned workspace, so only the output / residual geometry decides
+static bool k32_split_epilogue_ok(const GemmArgs& a) {
+  if ((a.Cout & 3) || (a.ldo & 3) || (a.o_zo & 3) || (((uintptr_t)a.out) & 15)) return false;
+  if (a.resid && ((a.ldr & 3) || (a.r_zo & 3) || (((uintptr_t)a.resid) & 15))) return false;
+  return true;
+}
 int small_class_tile(const GemmArgs& a) {   // 0: the default rules apply
   if (nominal_z(a) > 2 || a.math != MATH_F16X3 || a.ks != 3 || a.stride != 1 || a.ups || a.abl || a.poly || a.rups) return 0;
-  if ((a.Cin & 31) || a.Cin < 32 || !is_vec(a) || !k32_preferred()) return 0;
+  if ((a.Cin & 31) || a.Cin < 32 || !is_vec(a) || !k32_preferred() || !k32_split_epilogue_ok(a)) return 0;
   const long long M = (long long)a.Hout * a.Wout;
   if (M >= 4096) return XT_256x128K32;
   if (M >= 256) return XT_128x128K32;
@@ -1856,8 +1872,11 @@ bool splitk16(const GemmArgs& a) {
   // ASYRP_SPLITK32=1 (experiment, off by default): the same for the 32 x 32 maps on the 256-pixel form (4 x Cout/128 workgroups per image)
   static const bool on32 = [] { const char* e = getenv("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
   const bool m16 = a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16, m32 = on32 && a.Hout == 32 && a.Wout == 32 && a.Hin == 32 && a.Win == 32;
+  // (k32_split_epilogue_ok: the K32 float4 epilogue's rule -- Cout % 4, aligned rows -- so that the factor, the tile and the kernel
+  //  that is launched are decided by ONE predicate; with Cout = 6 at 16 x 16 the old rule promised a K32 split form that
+  //  k32spk_ok then refused)
   return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.poly && !a.s0 && !a.rups && (m16 || m32) &&
-         a.Cin >= 256 && (a.Cin % (m16 ? 32 * splitk16_ranges() : 64)) == 0 && is_vec(a) && k32_preferred();
+         a.Cin >= 256 && (a.Cin % (m16 ? 32 * splitk16_ranges() : 64)) == 0 && is_vec(a) && k32_preferred() && k32_split_epilogue_ok(a);
 }
 // the tile a split launch runs on (a function of the layer shape only, like the factor)
 int splitk_tile(const GemmArgs& a) {

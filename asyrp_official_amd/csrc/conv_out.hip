@@ -242,25 +242,36 @@ size_t conv_out_smem(int Cin, int TN) {
 }
 
 bool conv_out_two_tiles() {
-  // (round 4: on by default -- with the loads two chunks ahead the two-N-tile form measured 55.5 vs 46.0 TFLOP/s on the AFHQ head,
-  //  +0.2 % on that edit, profiles/r04a_*; ASYRP_CONV_OUT6=0 puts the head back on the implicit-GEMM tile)
+  // the 6-channel iDDPM head on two N tiles of this kernel (round 4: on by default -- with the loads two chunks ahead it measured
+  // 55.5 vs 46.0 TFLOP/s on the AFHQ head (Cin = 128), +0.2 % on that edit, profiles/r04a_*); ASYRP_CONV_OUT6=0 puts the head back on
+  // the implicit-GEMM tile
   static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return !(e && e[0] == '0'); }();
   return on;
 }
 bool conv_out_supported(const GemmArgs& a) {
-  return a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats &&
-         a.Cout * 9 <= (conv_out_two_tiles() ? 64 : 32) /* Cout = 6 (two N tiles) measured equal to the implicit-GEMM tile in round 2, 581 vs 587 us,
-                                                                 before the loads went two chunks ahead: ASYRP_CONV_OUT6=1 re-enables it for a new A/B */ && (a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout;
+  if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats)) return false;
+  if (!((a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout)) return false;
+  if (a.Cout * 9 <= 32) return true;                                  // one N tile (Cout = 3)
+  // two N tiles (Cout = 6): only where the A/B evidence is (AFHQ head, Cin = 128) and two workgroups still fit a CU -- at Cin = 256
+  // (ImageNet-ADM head) the form needs ~90 KB of LDS, one workgroup per CU, and measured 39 TFLOP/s, below the implicit-GEMM
+  // tile: that head stays on the tile
+  return a.Cout * 9 <= 64 && conv_out_two_tiles() && conv_out_smem(a.Cin, 2) <= 64 * 1024;
 }
 
 template <int NP, int TN = 1>
 static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
   const size_t smem = conv_out_smem(a.Cin, TN);
   dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
+  if (smem > 64 * 1024) {   // once per process and device (idempotent flag, as launch_k32)
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
   }
   hipLaunchKernelGGL((conv_out_kernel<TN, NP>), grid, block, smem, s, a);
   return hipGetLastError();

@@ -1913,7 +1913,10 @@ int asyrp_create(asyrp_engine** out, const asyrp_config* cfg, int max_batch, int
   if (cfg->n_levels < 1 || cfg->n_levels > ASYRP_MAX_LEVELS || cfg->ch % 32 != 0 || max_batch < 1 || cfg->n_delta < 0 ||
       cfg->n_delta > 4 || cfg->resolution % (1 << (cfg->n_levels - 1)) != 0)
     return fail(ASYRP_EINVAL, "unsupported configuration");
-  if (cfg->nominal_batch < 0 || cfg->nominal_batch > 4096) return fail(ASYRP_EINVAL, "nominal_batch outside [0, 4096] (0 = the default class, 32)");
+  if (!(cfg->nominal_batch == 0 || cfg->nominal_batch == 1 || cfg->nominal_batch == 2 || cfg->nominal_batch == 32))
+    return fail(ASYRP_EINVAL, "nominal_batch must be 0 (= 32, the default class), 1, 2 (the small class) or 32: the batch classes that are tested");
+  for (int i = 0; i < 5; ++i)
+    if (cfg->reserved[i] != 0) return fail(ASYRP_EINVAL, "asyrp_config.reserved must be zero");
   // no device call here: the engine can be created (and its parameter inventory listed) without a GPU;
   // device memory is first touched by asyrp_set_temb_freqs / asyrp_finalize_params.
   asyrp_engine* e = new asyrp_engine();
@@ -2771,7 +2774,7 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
       HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
       g.wpk = xg;
     }
-    if (tile == 17) {   // the first-convolution stencil (conv_in.hip): fp32 weights [tap][Cin][Cout] = `wp`
+    if (tile == XT_CONV_IN) {   // the first-convolution stencil (conv_in.hip): fp32 weights [tap][Cin][Cout] = `wp`
       g.tile = 0; g.alpha = 1.f;
       if (!conv_in_supported(g)) {
         for (void* p : tmp) (void)hipFree(p);
@@ -2872,7 +2875,7 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
     HIPCHK(launch_gemm1x1_pack(weight, xg, Cout, Cin, wscale, s));
     g.wpk = xg;
   }
-  const bool cin_kernel = (tile == 17);   // conv_in.hip: fp32 weights [tap][Cin][Cout], its own statistics rows
+  const bool cin_kernel = (tile == XT_CONV_IN);   // conv_in.hip: fp32 weights [tap][Cin][Cout], its own statistics rows
   if (cin_kernel) {
     float* wp;
     TRY(dalloc((size_t)ksize * ksize * Cin * Cout, &wp));

@@ -82,6 +82,7 @@ enum { XT_AUTO = 0, XT_256x128 = 1, XT_128x128 = 2, XT_64x128 = 3, XT_64x64 = 4,
        XT_256x128K32Q = 14 /* quad form for the 8 x 8 layers: four images per workgroup, split-K (GemmArgs.sk / part) */,
        XT_G1_256 = 15 /* gemm1x1.hip: barrier-free 1x1 kernel, 256 pixels x 128 channels, 8 waves; wpk = its fragment-major image */,
        XT_G1_128 = 16 /* the same with 128 pixels x 128 channels, 4 waves, two workgroups per CU */,
+       XT_CONV_IN = 17 /* conv_in.hip (the op-level test hooks only: the engine calls launch_conv_in itself) */,
        XT_256x32 = 12 /* Cout <= 32 */ };
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);            // dispatches on a.math
@@ -105,7 +106,7 @@ void gemm_work(const GemmArgs& a, double* flops, double* bytes);
 
 // conv_out.hip: the UNet's last 3x3 convolution (Cout = 3 / 6) with the taps folded into N; `a.wpk` = f16x3 image of the equivalent
 // 1x1 conv w1[tap*Cout + co][ci] (launch_pack_f16x3 with cout = 9*Cout, ks = 1), prologue scale/shift + SiLU mandatory
-bool conv_out_two_tiles();                     // ASYRP_CONV_OUT6=1: the 6-channel iDDPM head on two N tiles of conv_out.hip (experiment)
+bool conv_out_two_tiles();                     // the 6-channel iDDPM head on two N tiles of conv_out.hip (default; ASYRP_CONV_OUT6=0 disables; Cin <= 128 only)
 bool conv_out_supported(const GemmArgs& a);
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s);
 

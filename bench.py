@@ -140,10 +140,25 @@ def cpu_baseline(model_cpu_sd, betas, family="ddpm", learn_sigma=False, x_check=
         check = {"dual": step(x_check, ones * float(CHECK_DUAL[0]), ones * float(CHECK_DUAL[1]), eta=0.0, index=0, t_edit=T_EDIT,
                               hs_coeff=(1.0, 1.0)),
                  "inversion": step(x_check, ones * float(CHECK_INV[0]), ones * float(CHECK_INV[1]), eta=0)}
+    calib = None
+    if kind == "port":
+        # the port timed against the reference's own modules on ONE host (scripts/cpu_port_vs_reference.py, build container): how far
+        # the oracle's rate is from the reference's on the same sample, and whether their outputs differ
+        try:
+            with open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference_same_host.json")) as f:
+                c = json.load(f)
+            calib = {"port_over_reference_rate_same_host": c["port_over_reference_rate"],
+                     "outputs_bit_identical": c["outputs_bit_identical"],
+                     "estimated_reference_value": (1.0 / per_image) / c["port_over_reference_rate"],
+                     "source": "profiles/cpu_port_vs_reference_same_host.json (%d threads, build container)" % c["host"]["threads"]}
+        except (OSError, KeyError, ValueError):
+            calib = None
     res = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": kind,
            "sample": f"B=1: {len(inv_pairs)} inversion + {len(gen_pairs)} dual-decoder Asyrp steps timed ({t_inv:.2f} s, "
                      f"{t_gen:.2f} s per step), extrapolated to {N_INV - 1}+{N_GEN} steps; threads chosen by one warm forward each: "
                      + ", ".join(f"{n}: {s:.2f} s" for n, s in tried.items()) + f" (host has {avail} visible cores)"}
+    if calib:
+        res["port_vs_reference"] = calib
     return res, check
 
 
@@ -205,6 +220,26 @@ def paste_traffic(res, tpath, lib_path, dt, steps):
             fm["counter_frac_of_hbm_peak"] = fm["counter_GBps"] / (HBM_PEAK_TBS * 1e3)
 
 
+def bench_config(a):
+    """(family, learn_sigma, images per GPU, workload string) of `--config`: which BASELINE.json configuration a line is quoted on.
+    One function for the real run and the plumbing dry run, so an 8-GPU line cannot be quoted on the wrong configuration."""
+    family = {"celeba": "ddpm", "church": "ddpm", "afhq": "afhq", "imagenet": "imagenet"}[a.config]
+    B = a.batch or {"celeba": 32, "church": 32, "afhq": 64, "imagenet": 16}[a.config]
+    name = {"celeba": "CelebA-HQ DDPM", "church": "LSUN-Church DDPM", "afhq": "AFHQ-Dog iDDPM",
+            "imagenet": "ImageNet ADM (improved_ddpm UNet, 256 base ch)"}[a.config]
+    baseline = {"celeba": "BASELINE.json configs[1]", "church": "BASELINE.json configs[3] (batch 256 = 8 x 32 per GPU)",
+                "afhq": "BASELINE.json configs[2]", "imagenet": "BASELINE.json configs[4] (batch 128 = 8 x 16 per GPU)"}[a.config]
+    workload = (f"{name} 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
+                f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock")
+    return family, family != "ddpm", B, workload, baseline
+
+
+def engine_device_index(local_rank, backend, ndev):
+    """The device a rank builds its engine on: its LOCAL_RANK under RCCL (one process per GPU); ranks share devices only in the gloo
+    dry run on a box with fewer GPUs than ranks."""
+    return local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+
+
 def _setup_ranks(a, need_gpu):
     """Launcher contract: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per GPU); a rank reads
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment and joins the process group (nccl = RCCL; gloo = dry run)."""
@@ -221,7 +256,7 @@ def _setup_ranks(a, need_gpu):
     ndev = torch.cuda.device_count() if need_gpu else 0
     if need_gpu and backend == "nccl" and ndev < world:
         sys.exit(f"[bench] {world} ranks but only {ndev} GPU(s) visible (one process per GPU)")
-    dev_index = (local_rank if backend == "nccl" else local_rank % max(ndev, 1)) if need_gpu else -1
+    dev_index = engine_device_index(local_rank, backend, ndev) if need_gpu else -1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -275,16 +310,24 @@ def _plumbing_dry_run(a):
         return local, (gather_shards(local, B * world) if world > 1 else local)
     dt, (_, full) = _timed_steps(one_step, a, world, backend, "cpu", sync=lambda: None)
     seeds = [seed]
+    # the device index every rank WOULD build its engine on in the real (RCCL) run, and the configuration the line would be quoted on
+    devs = [engine_device_index(local_rank, "nccl", world)]
+    family, learn_sigma, B_real, workload, baseline_cfg = bench_config(argparse.Namespace(config=a.config, batch=0))
     if world > 1:
         got = [None] * world
-        dist.all_gather_object(got, seed)
-        seeds = got
+        dist.all_gather_object(got, (seed, devs[0], int(os.environ.get("LOCAL_RANK", "0"))))
+        seeds = [g_[0] for g_ in got]
+        devs = [g_[1] for g_ in got]
+        assert all(g_[1] == g_[2] for g_ in got), "a rank would build its engine on a device other than its LOCAL_RANK"
     if rank == 0:
         want = torch.cat([edit(2 * torch.rand((B, 3, 16, 16), generator=torch.Generator().manual_seed(sd_)) - 1) for sd_ in seeds])
         res = {"metric": BENCH_METRIC, "value": None, "unit": "images/s", "n_gpus": a.gpus, "world_size": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": 1e3 * dt / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dry_run": True, "data": "plumbing dry run: CPU tensors, stand-in per-image function, no engine",
                "backend": backend, "rank_seeds": seeds, "images_per_rank": B, "gathered_shape": list(full.shape),
+               "engine_device_index_per_rank": devs,
+               "config": {"workload": workload, "baseline_config": baseline_cfg, "batch_per_gpu": B_real, "learn_sigma": learn_sigma,
+                          "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)", "world_size": world},
                "gathered_equals_unsharded": bool(torch.equal(full, want))}
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -329,9 +372,7 @@ def main():
     from asyrp_official_amd.diffusion_utils import get_beta_schedule
     from asyrp_official_amd.sampler import gather_shards
 
-    family = {"celeba": "ddpm", "church": "ddpm", "afhq": "afhq", "imagenet": "imagenet"}[a.config]
-    learn_sigma = family != "ddpm"
-    B = a.batch or {"celeba": 32, "church": 32, "afhq": 64, "imagenet": 16}[a.config]
+    family, learn_sigma, B, workload, baseline_cfg = bench_config(a)
     torch.manual_seed(1234)                     # main.py:301 default seed
     if family == "ddpm":
         model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math, nominal_batch=a.nominal_batch)   # configs/church.yml has the same model block
@@ -416,10 +457,7 @@ def main():
             "dtype": {"f16x3": "f32 (conv products on f16 MFMA as exact two-term splits, fp32 accumulate)", "f32": "f32",
                       "f16": "f16 (FAST MODE: one f16 MFMA product per term, fp32 accumulate, fp32 activations in HBM; not "
                              "fp32-equivalent - see parity_check for its measured error)"}[a.conv_math], "data": "synthetic (seeded U[-1,1) images, seeded random-init weights)",
-            "config": {"workload": {"celeba": "CelebA-HQ DDPM", "church": "LSUN-Church DDPM", "afhq": "AFHQ-Dog iDDPM",
-                                    "imagenet": "ImageNet ADM (improved_ddpm UNet, 256 base ch)"}[a.config] +
-                                   f" 256x256, batch={B}/GPU, ninv={N_INV} (39 UNet evals) + ngen={N_GEN} "
-                                   f"Asyrp (t_edit={T_EDIT}: 20 dual-decoder + 20 single-decoder evals), 1 DeltaBlock",
+            "config": {"workload": workload, "baseline_config": baseline_cfg,
                        "batch_per_gpu": B, "parallelism": f"dp{world} (batch sharded, one all-gather of x_edit)",
                        "launcher": "self (bench.py re-executed under torch.distributed.run)"
                        if os.environ.get("ASYRP_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),

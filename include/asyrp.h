@@ -81,8 +81,10 @@ typedef struct asyrp_config {
                                    * this engine, whatever its B, runs the same kernels on an image, so an image alone equals its row
                                    * of a batch bit for bit.  1 or 2 = the small class (single-image serving / the reference's
                                    * bs_train = 1): more, smaller workgroups and K split up to 8 ways.  Results of different classes
-                                   * agree to fp32 rounding (as any two tile shapes do), not bitwise.  (Was reserved[0] = 0.) */
-  int32_t reserved[5];
+                                   * agree to fp32 rounding (as any two tile shapes do), not bitwise.  Accepted values: 0, 1, 2, 32
+                                   * (the classes that are tested against the fixtures); anything else is ASYRP_EINVAL.
+                                   * (ABI v8: was reserved[0] in v7.) */
+  int32_t reserved[5];            /* must be zero (asyrp_create rejects anything else, so that a later field cannot be set by accident) */
 } asyrp_config;
 
 typedef struct asyrp_engine asyrp_engine;
@@ -93,7 +95,7 @@ typedef struct asyrp_engine asyrp_engine;
 #pragma GCC visibility push(default)
 #endif
 /* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
-#define ASYRP_ABI_VERSION 7
+#define ASYRP_ABI_VERSION 8
 int asyrp_abi_version(void);
 
 /* Last error text of the calling thread ("" if none). */

@@ -67,10 +67,11 @@ constexpr int BN = 128, B_BYTES = BN * 64;
 constexpr long long TILE_ACT_FLOATS = 324LL * 128;   // one tile's 18 x 18 halo x 128 channels (fp32), its own region of the buffer
 
 // WINO = false: the product's main tile.  WINO = true: the F(2,3) tiling described above.
-template <bool WINO, int MINW>
+template <bool WINO, int MINW, int STAGE>
 __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Float16* __restrict__ wg, size_t wbytes, const float* __restrict__ act,
                                                                       size_t act_floats, const float* __restrict__ scsh, float* __restrict__ out,
-                                                                      int nch /* 16-channel chunks */, int stage) {
+                                                                      int nch /* 16-channel chunks */) {
+  constexpr int stage = STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WINO ? 16 : 8, NT = NW * 64;
   constexpr int NSLICE = WINO ? 8 : 2;                        // 8-KB slices per K = 32 step
@@ -104,12 +105,26 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
     const float4 s0 = *reinterpret_cast<const float4*>(scsh + c), s1 = *reinterpret_cast<const float4*>(scsh + c + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(scsh + 128 + c), h1 = *reinterpret_cast<const float4*>(scsh + 128 + c + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    // stage: 1 = as the product, 2 = loads + split only (no GroupNorm affine / SiLU), 3 = no global loads (values from registers)
     auto activated = [&](int pix, float (&t)[8]) {
-      const float* src = atile + (size_t)pix * 128 + c;
-      const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+      float4 v0, v1;
+      if (stage == 3) {
+        v0 = make_float4(0.37f + pix, -1.21f, 0.05f * chunk, 2.5f);
+        v1 = make_float4(-0.6f, 0.93f - pix, 1.7f, -0.11f * chunk);
+        asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w), "+v"(v1.x), "+v"(v1.y), "+v"(v1.z), "+v"(v1.w));
+      } else {
+        const float* src = atile + (size_t)pix * 128 + c;
+        v0 = *reinterpret_cast<const float4*>(src);
+        v1 = *reinterpret_cast<const float4*>(src + 4);
+      }
       const float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (stage == 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = silu_fast(__builtin_fmaf(r[j], sc[j], sh[j]));
+        for (int j = 0; j < 8; ++j) t[j] = r[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = silu_fast(__builtin_fmaf(r[j], sc[j], sh[j]));
+      }
     };
     if (!WINO) {
 #pragma unroll
@@ -152,6 +167,58 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
     }
   };
 
+  // stage == 4 (DIRECT): the raw fp32 halo of a chunk travels HBM/L2 -> LDS by LDS-DMA two steps ahead (no registers, no exposed
+  // global latency), in the pixel-major layout [pixel][16 floats] inside the chunk's own halo buffer (same size as the hi/lo image);
+  // the staging pass then reads it from LDS, converts and writes the hi/lo planes in place (one extra barrier between the reads
+  // and the writes)
+  auto issue_halo = [&](int chunk, int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int pc = wave + k * 8;
+      if (pc < 21) {
+        int pixel = 16 * pc + (lane >> 2);
+        pixel = pixel < 324 ? pixel : 323;
+        const float* src = atile + (size_t)pixel * 128 + ((chunk * 16) & 127) + (lane & 3) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + buf * A_BYTES + pc * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto convert_halo = [&](int chunk, int buf) {
+    const int hf = tid & 1;
+    const int c = (chunk * 16 + hf * 8) & 127;
+    const float4 s0 = *reinterpret_cast<const float4*>(scsh + c), s1 = *reinterpret_cast<const float4*>(scsh + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(scsh + 128 + c), h1 = *reinterpret_cast<const float4*>(scsh + 128 + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float4 raw[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * NT;
+      const int pix = (u < 648 ? u : 647) >> 1;
+      const char* srcl = As + buf * A_BYTES + pix * 64 + hf * 32;
+      raw[i][0] = *reinterpret_cast<const float4*>(srcl);
+      raw[i][1] = *reinterpret_cast<const float4*>(srcl + 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * NT;
+      if (u >= 648) break;
+      const int pix = u >> 1;
+      const float r[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = silu_fast(__builtin_fmaf(r[j], sc[j], sh[j]));
+      h8 hi, lo;
+      split8(t, hi, lo);
+      char* dst = As + buf * A_BYTES + (hf * PLANE + pix) * 16;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + 2 * PLANE * 16) = lo;
+    }
+  };
+
   const int r16 = lane & 15, kq = lane >> 4, tp = kq >> 1, kh = kq & 1;
   const int a_lane = WINO ? plane * (4 * PLANE * 16) + (kh * PLANE + wm * 64 + r16) * 16 : (kh * PLANE + (wm * 4) * TW + r16) * 16;
   constexpr int A_TM = WINO ? 256 : TW * 16;
@@ -171,8 +238,15 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
   __syncthreads();
 
   const int nsteps = nch * NTAPS / 2;
-  int c0 = 0, t0 = 0, staged = 0;
+  int c0 = 0, t0 = 0, staged = 0, dma_issued = 0;
   for (int s = 0; s < nsteps; ++s) {
+    if (!WINO && stage == 4) {   // the chunk whose conversion falls at the end of step s + 1: the second slice of step s + 2
+      const int nd = (2 * s + 5) / NTAPS;
+      if (nd > dma_issued && nd < nch) {
+        issue_halo(nd, nd & 1);
+        dma_issued = nd;
+      }
+    }
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
     int offA0, offA1;
@@ -228,7 +302,17 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
     if (t0 >= NTAPS) { t0 -= NTAPS; ++c0; }
     const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
     if (stage && need > staged && need < nch) {
-      stage_chunk(need, need & 1);
+      if (!WINO && stage == 4) {
+        if (dma_issued < need) {   // (first steps of a tile: the request could not be two steps ahead)
+          issue_halo(need, need & 1);
+          dma_issued = need;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        convert_halo(need, need & 1);
+      } else {
+        stage_chunk(need, need & 1);
+      }
       staged = need;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,11 +396,12 @@ static void read_clk_power(double* mhz, double* watts) {   // the busiest card o
   }
 }
 
-template <bool WINO, int MINW>
-static void run(const char* name, int nch, int stage, const _Float16* w, size_t wbytes, const float* act, size_t act_floats, const float* scsh, float* out) {
+template <bool WINO, int MINW, int STAGE>
+static void run(const char* name, int nch, const _Float16* w, size_t wbytes, const float* act, size_t act_floats, const float* scsh, float* out) {
   constexpr int NSLOT = WINO ? 1 : 2, SLOT = (WINO ? 8 : 2) * B_BYTES, A_BYTES = (WINO ? 4 * 4 * 144 : 4 * 336) * 16;
   const size_t smem = NSLOT * (size_t)SLOT + 2 * (size_t)A_BYTES;
-  auto k = tile_kernel<WINO, MINW>;
+  constexpr int stage = STAGE;
+  auto k = tile_kernel<WINO, MINW, STAGE>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
     printf("%-58s: LDS %zu B refused\n", name, smem);
     return;
@@ -324,17 +409,17 @@ static void run(const char* name, int nch, int stage, const _Float16* w, size_t 
   const int tiles = 8192, NT = WINO ? 1024 : 512;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch, stage);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch);
   if (hipDeviceSynchronize() != hipSuccess) { printf("%-58s: launch failed\n", name); return; }
   // about 2.5 s of back-to-back launches: the power controller settles, sclk / W are sampled from 0.8 s on
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch, stage);
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch);
   (void)hipEventRecord(e1, 0);
   (void)hipEventSynchronize(e1);
   float ms1; (void)hipEventElapsedTime(&ms1, e0, e1);
   const int launches = (int)(2500.0 / ms1) + 1;
   (void)hipEventRecord(e0, 0);
-  for (int j = 0; j < launches; ++j) hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch, stage);
+  for (int j = 0; j < launches; ++j) hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch);
   (void)hipEventRecord(e1, 0);
   double mhz = 0, watts = 0; int n = 0;
   usleep(800 * 1000);
@@ -349,7 +434,7 @@ static void run(const char* name, int nch, int stage, const _Float16* w, size_t 
   const double us = ms * 1e3 / launches;
   const double tf = (double)tiles * 256 * 128 * (nch * 16.0) * 9 * 2 / (us * 1e-6) / 1e12;   // the layer's direct-convolution flops
   printf("%-58s %4d->128 %s: %8.1f us per launch = %6.1f TFLOP/s direct-equivalent; LDS %3zu KB; sclk %5.0f MHz %5.0f W (n=%d)\n", name, nch * 16,
-         stage ? "staging on " : "staging off", us, tf, smem / 1024, n ? mhz / n : -1.0, n ? watts / n : -1.0, n);
+         stage == 0 ? "staging off" : stage == 1 ? "staging on " : stage == 2 ? "stage: loads+split only" : stage == 3 ? "stage: no global loads" : "stage: LDS-DMA 2 steps ahead", us, tf, smem / 1024, n ? mhz / n : -1.0, n ? watts / n : -1.0, n);
   fflush(stdout);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
@@ -367,12 +452,23 @@ int main() {
   hipLaunchKernelGGL(fill_weights, dim3(1024), dim3(256), 0, 0, w, wbytes / 16);
   hipLaunchKernelGGL(fill_act, dim3(4096), dim3(256), 0, 0, act, act_floats);
   (void)hipDeviceSynchronize();
+  const bool quick = getenv("TILE_SHAPES_STAGING") != nullptr;   // the staging ablations of the DIRECT skeleton only
   for (int rep = 0; rep < 2; ++rep) {
     for (int nch : {8, 16}) {
-      for (int stage : {1, 0}) {
-        run<false, 4>("DIRECT main tile: 8 waves, 2 WG/CU", nch, stage, w, wbytes, act, act_floats, scsh, out);
-        run<true, 4>("WINO F(2,3): 16 waves, 1 WG/CU, single weight slot", nch, stage, w, wbytes, act, act_floats, scsh, out);
+      const char* D = "DIRECT main tile: 8 waves, 2 WG/CU";
+      const char* W = "WINO F(2,3): 16 waves, 1 WG/CU, single weight slot";
+      if (quick) {
+        run<false, 4, 1>(D, nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 4>(D, nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 2>(D, nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 3>(D, nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 0>(D, nch, w, wbytes, act, act_floats, scsh, out);
+        continue;
       }
+      run<false, 4, 1>(D, nch, w, wbytes, act, act_floats, scsh, out);
+      run<true, 4, 1>(W, nch, w, wbytes, act, act_floats, scsh, out);
+      run<false, 4, 0>(D, nch, w, wbytes, act, act_floats, scsh, out);
+      run<true, 4, 0>(W, nch, w, wbytes, act, act_floats, scsh, out);
     }
   }
   return 0;

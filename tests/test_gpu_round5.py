@@ -168,3 +168,18 @@ def test_run_to_run_determinism_training_step():
         return [x0t.detach()] + [p.grad for p in m.layer_0.parameters()]
 
     _same_bits(step, n=2)
+
+
+@pytest.mark.parametrize("Cout", [6, 130])
+def test_conv3x3_at_16x16_with_cout_not_a_multiple_of_4(Cout):
+    """a 16 x 16 layer with Cin = 256 qualifies for the 2-way split-K K32 form by shape, but with Cout % 4 != 0 the K32
+    float4 epilogue does not apply; the split factor, the tile and the launched kernel must be decided by ONE predicate (the launch
+    used to fall through to a tile that was not the one the split rule promised).  Automatic tile choice, against torch fp32."""
+    from test_gpu_ops import TIGHT, hip_conv, ref_conv
+    B, Cin, H = 2, 256, 16
+    x = hash_normal(f"r5.c16.x.{Cout}", (B, Cin, H, H))
+    w = hash_uniform(f"r5.c16.w.{Cout}", (Cout, Cin, 3, 3), -1, 1) / (Cin * 9) ** 0.5
+    b = 0.1 * hash_uniform(f"r5.c16.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform("r5.c16.g", (Cin,)), 0.1 * hash_uniform("r5.c16.be", (Cin,)))
+    got = hip_conv(x, w, b, gn=gn, silu=True)
+    assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv3x3 16x16 Cin=256 Cout={Cout}", **TIGHT)

@@ -346,3 +346,51 @@ def test_bench_eight_rank_plumbing_dry_run_under_gloo():
     assert len(set(res["rank_seeds"])) == 8 and res["rank_seeds"] == [1234 + r_ for r_ in range(8)]
     assert res["gathered_shape"] == [24, 3, 16, 16] and res["gathered_equals_unsharded"] is True
     assert res["metric"].startswith("edited images/sec")
+    # every rank builds its engine on its LOCAL_RANK's device (one process per GPU)
+    assert res["engine_device_index_per_rank"] == list(range(8))
+    assert res["config"]["batch_per_gpu"] == 32 and "configs[1]" in res["config"]["baseline_config"]
+
+
+@pytest.mark.parametrize("config,batch,tag,name", [("church", 32, "configs[3]", "LSUN-Church"), ("imagenet", 16, "configs[4]", "ImageNet ADM")])
+def test_bench_eight_rank_dry_run_names_the_sharded_baseline_configs(config, batch, tag, name):
+    """`--config church --gpus 8` / `--config imagenet --gpus 8` (BASELINE configs 4 and 5: batch 256 / 128 sharded over 8 GPUs) report
+    32 / 16 images per GPU and name the configuration, so the first real 8-GPU line cannot be quoted on the wrong one."""
+    import json
+    import subprocess
+    env = dict(os.environ, ASYRP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--config", config,
+                        "--plumbing-dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["engine_device_index_per_rank"] == list(range(8))
+    assert res["config"]["batch_per_gpu"] == batch and tag in res["config"]["baseline_config"] and name in res["config"]["workload"]
+    assert res["config"]["learn_sigma"] == (config == "imagenet")
+
+
+def test_batch_class_values_are_validated_before_they_reach_the_library():
+    """asyrp_config.nominal_batch accepts the tested classes only (0 = 32, 1, 2, 32): the Python mirror raises before an
+    engine is built, and asyrp_create repeats the check (and requires the reserved words to be zero) for any other binding."""
+    from asyrp_official_amd import DDPM
+    sys.path.insert(0, ROOT)
+    import bench
+    for ok in (0, 1, 2, 32):
+        DDPM(bench.celeba_namespace(), max_batch=1, nominal_batch=ok)
+    for bad in (-1, 3, 16, 64, 4096):
+        with pytest.raises(ValueError):
+            DDPM(bench.celeba_namespace(), max_batch=1, nominal_batch=bad)
+    src = open(os.path.join(ROOT, "asyrp_official_amd", "csrc", "engine.hip")).read()
+    assert "asyrp_config.reserved must be zero" in src and "nominal_batch must be 0" in src
+
+
+def test_data_parallel_replication_fails_loudly():
+    """nn.DataParallel with N > 1 devices (the reference's only multi-GPU form, diffusion_latent.py:591) must not replicate the engine
+    mirror: replicas are shallow copies that would share one engine handle across threads and devices."""
+    from asyrp_official_amd import DDPM, AsyrpDeviceError, i_DDPM
+    sys.path.insert(0, ROOT)
+    import bench
+    for m in (DDPM(bench.celeba_namespace(), max_batch=1), i_DDPM("AFHQ", max_batch=1)):
+        with pytest.raises(AsyrpDeviceError, match="one process per GPU"):
+            m._replicate_for_data_parallel()
+
