@@ -1359,6 +1359,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     float add4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) add4[j] = nok ? ((has_b ? p.bias[nq + j] : 0.f) + (has_c ? cadd[nq + j] : 0.f)) : 0.f;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     // item i of row block tm: block row m = prow + i * RSTEP -> output pixel, residual pixel, inside the image?
     auto geom = [&](int tm, int i, int& pixel, int& rpix) -> bool {
       const int m = prow + i * RSTEP;
@@ -1373,19 +1374,15 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       v.z = (a.z + add4[2]) + r.z;
       v.w = (a.w + add4[3]) + r.w;
     };
-    // GroupNorm partials (round 5): the 4 x NV values of a channel that a lane stores are summed in fp32 (packed v_pk_add_f32 /
-    // v_pk_fma_f32, fixed order) and join the double-precision chain (lanes -> wave rows -> tiles -> gn_finalize2) as ONE pair of
-    // sums per lane and channel.  Before, every value was converted, squared and added in f64 (half-rate instructions: 2.8 % of a
-    // main-tile launch, profiles/r05a_k32_product_kernel_*, and 16 live registers).  <= 15 roundings of 2^-24 per partial sum, with
-    // random signs over the >= 64 partials of a group: 1e-8-class relative error on a group's moments, below the reference's own
-    // fp32 moments.  Deterministic and batch-invariant as before (same values, same order).
-    f2 q1a = {0.f, 0.f}, q1b = {0.f, 0.f}, q2a = {0.f, 0.f}, q2b = {0.f, 0.f};
+    // (round 5, measured and NOT kept: the lane's 4 x NV values per channel summed in fp32 (packed adds / fmas) before joining the f64
+    //  chain -- 118 instead of 126 VGPRs, but only +0.5 % on a launch that emits statistics (the cost of the statistics is the
+    //  shuffles, the barrier and the LDS reduction, not the f64 arithmetic) and 5 % more mean error on a 39-step trajectory:
+    //  profiles/r05d_k32_prod_fp32_partials_NEGATIVE.txt)
     auto stat4 = [&](const float4& v) {
-      const f2 a = {v.x, v.y}, b = {v.z, v.w};
-      q1a += a;
-      q1b += b;
-      q2a = __builtin_elementwise_fma(a, a, q2a);
-      q2b = __builtin_elementwise_fma(b, b, q2b);
+      s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
+      s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+      s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
+      s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
     };
     if (full) {
       // straight-line code (no per-element predicate, so hipcc counts vmcnt instead of draining it): the residual rows of block
@@ -1449,8 +1446,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     }
     K32_STAMP(3);
     if (want_stats) {   // fixed-order reduction over the lanes that hold the same channel quad, then over the wave rows below
-      double s1[4] = {(double)q1a[0], (double)q1a[1], (double)q1b[0], (double)q1b[1]};
-      double s2[4] = {(double)q2a[0], (double)q2a[1], (double)q2b[0], (double)q2b[1]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
