@@ -384,25 +384,20 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
   // its use to save registers, which is exactly the exposed round trip per step the ring exists to avoid)
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- stage Q: [plane][ks][query tile] blocks of 1 KiB, copied as they are (lane-linear) ----
+  // ---- stage Q: [plane][ks][query tile] blocks of 1 KiB, copied as they are (lane-linear) by LDS-DMA (round 5): every block is one
+  // global_load_lds_dwordx4 of a wave, all of a wave's blocks are in flight at once and no register is involved (the round-3 form
+  // moved them through four 16-byte registers per thread in two dependent rounds: 4.3 us of a 21-us workgroup) ----
   {
-    const int nq = (NP == 1 ? 1 : 2) * nks * 2 * 64;   // 16-B pieces
+    const int nblk = (NP == 1 ? 1 : 2) * nks * 2;      // 1-KiB blocks: (plane, ks, query tile); Qs sits at LDS offset 0, <= 64 KB
     const int qt0 = q0 >> 4;
-    for (int i0 = tid; i0 < nq; i0 += 4 * 512) {     // four 16-B loads in flight per thread, then the four LDS writes
-      h8 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = min(i0 + u * 512, nq - 1);
-        const int ln = i & 63, qt = (i >> 6) & 1, ks = (i >> 7) % nks, pl = (i >> 7) / nks;
-        const int tt = min(qt0 + qt, (T >> 4) - 1);
-        v[u] = *reinterpret_cast<const h8*>((pl ? PL : PH) + ((long long)(tt * ldb + qcs + ks) * 64 + ln) * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 512;
-        if (i < nq) *reinterpret_cast<h8*>(Qs + (size_t)i * 16) = v[u];
-      }
+    for (int blk = wave; blk < nblk; blk += 8) {
+      const int qtile = blk & 1, ks = (blk >> 1) % nks, pl = (blk >> 1) / nks;
+      const int tt = min(qt0 + qtile, (T >> 4) - 1);
+      const _Float16* src = (pl ? PL : PH) + ((long long)(tt * ldb + qcs + ks) * 64 + lane) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Qs + (size_t)blk * 1024), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   ATTN_STAMP(1);
@@ -485,6 +480,10 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     if (g == 0) red[wave * 32 + qt * 16 + r16] = mx[qt];
   }
   __syncthreads();
+  // (round 5) the probabilities go to phase 2 UNNORMALISED: e = exp(s - max) (in (0, 1], times 2^10, split hi / lo); the row sums
+  // travel through `red` under the same barrier as the P tile and the output is divided once at the end, O = (V^T e) / sum.  The
+  // round-3 form normalised every e first (one more barrier and a correctly rounded division per score); the two orders agree to
+  // fp32 rounding.
   float sum[2] = {0.f, 0.f};
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -504,15 +503,7 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     sum[qt] += __shfl_xor(sum[qt], 32);
     if (g == 0) red[256 + wave * 32 + qt * 16 + r16] = sum[qt];
   }
-  __syncthreads();
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += red[256 + w * 32 + qt * 16 + r16];   // fixed order: deterministic
-    sum[qt] = t;
-  }
-  // p * 2^10 as hi/lo -> LDS in the B-operand layout of phase 2: k group kq of a 32-key step = keys 8kq .. 8kq+7
+  // e * 2^10 as hi/lo -> LDS in the B-operand layout of phase 2: k group kq of a 32-key step = keys 8kq .. 8kq+7
 #pragma unroll
   for (int i = 0; i < NKTW; ++i) {
     if (!kval[i]) continue;
@@ -523,7 +514,7 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
       h4 hi, lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = __fdiv_rn(s[i][qt][r], sum[qt]) * P_SCALE;
+        const float v = s[i][qt][r] * P_SCALE;
         const _Float16 hh = (_Float16)v;
         hi[r] = hh;
         lo[r] = (_Float16)(v - (float)hh);
@@ -568,10 +559,14 @@ __global__ void __launch_bounds__(512, 1) attn_planes_kernel(const AttnArgs p) {
     ATTN_STAMP(4);
     // accumulator: column = query r16 of the tile, rows = channels 4g .. 4g+3 of the tile: 16 contiguous bytes of out[q][.]
     const int q = q0 + qt * 16 + r16;
+    float tsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tsum += red[256 + w * 32 + qt * 16 + r16];   // this lane's query: fixed order, deterministic
+    const float inv = __fdiv_rn(P_UNSCALE, tsum);
     if (q < T) {
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
-        float4 v = make_float4(o[jj][0] * P_UNSCALE, o[jj][1] * P_UNSCALE, o[jj][2] * P_UNSCALE, o[jj][3] * P_UNSCALE);
+        float4 v = make_float4(o[jj][0] * inv, o[jj][1] * inv, o[jj][2] * inv, o[jj][3] * inv);
         *reinterpret_cast<float4*>(outz + (long long)q * p.ldo + (dtb + 4 * jj) * 16 + 4 * g) = v;
       }
     }

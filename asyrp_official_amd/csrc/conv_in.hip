@@ -117,6 +117,177 @@ __global__ void __launch_bounds__(CI_NT, 2) conv_in_kernel(const GemmArgs p) {
   }
 }
 
+// =====================================================================================================================
+// conv_in_mfma_kernel (round 5).  The stencil above is VALU-bound, not HBM-bound: 27 x 128 FMAs per pixel are 123 us of packed
+// FMAs per launch at B = 32 even at full issue rate, plus 73 us of half-rate f64 statistics, against 195 us for its 1.07 GB of
+// output at the chip's measured store rate (5.5 TB/s, profiles/r04m_*): 318 us, 3.5 TB/s.  Here the 27 taps
+// are the K dimension of ONE K = 32 matrix step (k = tap * 3 + ci, 27..31 zero) on v_mfma_f32_16x16x32_f16 with the engine's exact
+// two-term operand split (x_lo w_hi + x_hi w_hi + x_hi w_lo, fp32 accumulate: 48 instructions per wave instead of 1 728 FMAs per
+// lane), in the main tile's shape -- 8 waves x (64 pixels x 64 channels) on a 16 x 16 patch x 128 channels -- and leaves through
+// the main tile's epilogue (wave-private LDS slabs -> float4 stores of 256 contiguous bytes per pixel, f64 statistics).  What is
+// left is the store stream.
+//   A: every lane gathers its own fragments from the fp32 halo in LDS (4 row blocks x 8 values) and splits them in registers.
+//   B: the lane's 8 weights per column block come from the fp32 [tap][3][Cout] image (L2-hot), scaled by 2^10 before the split
+//      (the split's lo term stays normal, as for every other weight image), undone by alpha = 2^-10 in the epilogue.
+// Results differ from the fp32 stencil by the dropped x_lo w_lo terms (2^-22 relative per product); batch-invariant bit for bit.
+// =====================================================================================================================
+typedef _Float16 cih8 __attribute__((ext_vector_type(8)));
+typedef float cif4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ci_split8(const float (&v)[8], cih8& hi, cih8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float c = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+    const _Float16 h = (_Float16)c;
+    hi[j] = h;
+    lo[j] = (_Float16)(c - (float)h);
+  }
+}
+
+constexpr int CIM_NT = 512, CIM_BN = 128, CIM_EP = 68;
+
+__global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float halo[CI_T * CI_PITCH];
+  __shared__ __attribute__((aligned(16))) float slabs[8 * 16 * CIM_EP];      // one 16-pixel x 64-channel slab per wave
+  __shared__ double red[4 * CIM_BN * 2];                                     // [wave row][channel][2]
+  const int tid = threadIdx.x, lane = tid & 63, zo = blockIdx.z;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int tiles_x = (p.Wout + CI_P - 1) / CI_P;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * CI_P, ox0 = tx * CI_P, n0 = blockIdx.y * CIM_BN;
+  const int Cout = p.Cout;
+  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
+  for (int i = tid; i < CI_T * CI_T * 3; i += CIM_NT) {
+    const int c = i % 3, pix = i / 3, iy = pix / CI_T, ix = pix - iy * CI_T;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    halo[iy * CI_PITCH + ix * 3 + c] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? a0[((long long)gy * p.Win + gx) * p.lda0 + c] : 0.f;
+  }
+  // ---- B fragments: lane = (column c16 of a 16-channel block, k group kq): w[k = 8 kq + j][n] * 2^10, two-term split ----
+  const int r16 = lane & 15, kq = lane >> 4;
+  cih8 bh[4], bl[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = n0 + wn * 64 + tn * 16 + r16;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * kq + j;
+      wv[j] = (k < 27 && n < Cout) ? p.w[(long long)k * p.ldb + n] * 1024.f : 0.f;
+    }
+    ci_split8(wv, bh[tn], bl[tn]);
+  }
+  __syncthreads();
+  // ---- A fragments: row r16 of row block tm = patch pixel (py = wm * 4 + tm, px = r16); k = ky * 9 + (kx * 3 + ci) ----
+  cif4 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = cif4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int py = wm * 4 + tm;
+    float av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * kq + j, ky = k / 9, r = k - ky * 9;           // (k >= 27: ky = 3, never read)
+      av[j] = (k < 27) ? halo[(py + ky) * CI_PITCH + r16 * 3 + r] : 0.f;
+    }
+    cih8 ah, al;
+    ci_split8(av, ah, al);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: the K32 main tile's (conv_f16x3.hip): C/D layout col = lane & 15 (channel), rows 4 (lane >> 4) + r (pixels) ->
+  // wave-private slab -> float4 = four consecutive channels of one pixel ----
+  float* const ep = slabs + wave * (16 * CIM_EP);
+  const int g = lane >> 4, c4 = lane & 15, prow = lane >> 4;      // 16 channel quads x 4 pixel rows per pass, 4 passes per row block
+  const int nq = n0 + wn * 64 + c4 * 4;
+  const bool nok = nq < Cout;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + nq);
+  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+  const bool want_stats = (p.stats != nullptr);
+  const bool full = (n0 + CIM_BN <= Cout) && (oy0 + CI_P <= p.Hout) && (ox0 + CI_P <= p.Wout);
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr float ALPHA = 1.0f / 1024.f;
+  auto stat4 = [&](const float4& v) {
+    s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
+    s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+    s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
+    s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+  };
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(4 * g + r) * CIM_EP + tn * 16 + r16] = acc[tm][tn][r] * ALPHA;
+    asm volatile("" ::: "memory");
+    const int oy = oy0 + wm * 4 + tm;
+    if (full) {   // straight-line stores (no per-element predicate: hipcc counts vmcnt instead of draining it before every store)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = prow + 4 * i;
+        const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
+        const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+        *reinterpret_cast<float4*>(outz + ((long long)oy * p.Wout + ox0 + m) * p.ldo + nq) = v;
+        if (want_stats) stat4(v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = prow + 4 * i;
+        const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
+        const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+        if (nok && oy < p.Hout && ox0 + m < p.Wout) {
+          *reinterpret_cast<float4*>(outz + ((long long)oy * p.Wout + ox0 + m) * p.ldo + nq) = v;
+          if (want_stats) stat4(v);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (want_stats) {   // fixed order: in-lane -> the four lanes (g) that hold a channel quad -> the wave rows through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16); s2[j] += __shfl_xor(s2[j], 16);
+      s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double* d = red + ((size_t)wm * CIM_BN + wn * 64 + c4 * 4 + j) * 2;
+        d[0] = s1[j];
+        d[1] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < CIM_BN; c += CIM_NT) {
+      if (n0 + c < Cout) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += red[((size_t)w * CIM_BN + c) * 2];
+          b += red[((size_t)w * CIM_BN + c) * 2 + 1];
+        }
+        double* dst = p.stats + (((size_t)zo * gridDim.x + blockIdx.x) * Cout + n0 + c) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
+  }
+}
+
+// A/B switch: ASYRP_CONV_IN_MFMA=0 keeps the fp32 stencil (exact fp32 products, VALU-bound)
+static bool conv_in_mfma_enabled() {
+  static const bool on = [] { const char* e = getenv("ASYRP_CONV_IN_MFMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 bool conv_in_supported(const GemmArgs& a) {
   if (!(a.ks == 3 && a.stride == 1 && !a.ups && a.pad == 1 && a.Cin == 3 && !a.a1 && !a.pscale && !a.silu && !a.resid && !a.chan_add)) return false;
   if (!a.w || a.bT || a.ZI > 1 || a.s0 || a.sk > 1 || a.poly || a.o16h) return false;
@@ -129,6 +300,10 @@ int conv_in_stat_blocks(const GemmArgs& a) { return ((a.Hout + CI_P - 1) / CI_P)
 
 hipError_t launch_conv_in(const GemmArgs& a, hipStream_t s) {
   if (!conv_in_supported(a)) return hipErrorInvalidValue;
+  if (conv_in_mfma_enabled()) {
+    hipLaunchKernelGGL(conv_in_mfma_kernel, dim3(conv_in_stat_blocks(a), (a.Cout + CIM_BN - 1) / CIM_BN, a.Z), dim3(CIM_NT), 0, s, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(conv_in_kernel, dim3(conv_in_stat_blocks(a), 1, a.Z), dim3(CI_NT), 0, s, a);
   return hipGetLastError();
 }

@@ -586,7 +586,11 @@ def test_first_convolution_stencil_kernel(B, Cout, H, W):
     w = hash_uniform(f"cin.w.{Cout}", (Cout, 3, 3, 3), -1, 1) / 27 ** 0.5
     b = 0.1 * hash_uniform(f"cin.b.{Cout}", (Cout,))
     got = hip_conv(x, w, b, tile=17)
-    assert_close(got, ref_conv(x, w, b), what="conv_in stencil", rtol=1e-5, atol=2e-6)
+    # round 5: the default is the one-K-step MFMA form (two-term f16 operand split: 2^-22 relative per product, <= 27 products per
+    # output); ASYRP_CONV_IN_MFMA=0 keeps the fp32 stencil with its exact fp32 products
+    import os
+    tol = dict(rtol=1e-5, atol=2e-6) if os.environ.get("ASYRP_CONV_IN_MFMA", "1")[:1] == "0" else dict(rtol=1e-4, atol=4e-6)
+    assert_close(got, ref_conv(x, w, b), what="conv_in kernel", **tol)
     if B > 1:
         alone = hip_conv(x[B - 1:B], w, b, tile=17)
         assert torch.equal(alone[0], got[B - 1]), "conv_in stencil: result depends on the batch"
@@ -617,7 +621,7 @@ def test_first_convolution_stencil_kernel_statistics(H, W, Cout, offset):
                                          _p(y), _p(sc), _p(sh), None))
     torch.cuda.synchronize()
     want_y = F.conv2d(x, w, b, padding=1)
-    assert_close(y.cpu(), want_y, what="conv", rtol=1e-5, atol=2e-6 * max(1.0, offset))
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-5, atol=4e-6 * max(1.0, offset))
     got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
     want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
     assert_close(got_gn, want_gn, what="fused GN", rtol=1e-3, atol=1e-4)
