@@ -146,137 +146,198 @@ __device__ __forceinline__ void ci_split8(const float (&v)[8], cih8& hi, cih8& l
 
 constexpr int CIM_NT = 512, CIM_BN = 128, CIM_EP = 68;
 
+// Persistent (second measurement of round 5: one tile per workgroup ran at 300 us against the stencil's 318 -- every workgroup paid
+// the weight fragments (32 strided loads + splits per lane), the halo's load latency and the launch ramp again): a workgroup now
+// keeps its B fragments in registers and walks tiles t = blockIdx.x, + gridDim.x, ... of its N block; the halo of tile t + 1 is
+// requested before tile t's matrix step and written to LDS behind it, so that only the first tile of a workgroup waits for memory.
 __global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float halo[CI_T * CI_PITCH];
   __shared__ __attribute__((aligned(16))) float slabs[8 * 16 * CIM_EP];      // one 16-pixel x 64-channel slab per wave
   __shared__ double red[4 * CIM_BN * 2];                                     // [wave row][channel][2]
-  const int tid = threadIdx.x, lane = tid & 63, zo = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-  const int tiles_x = (p.Wout + CI_P - 1) / CI_P;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * CI_P, ox0 = tx * CI_P, n0 = blockIdx.y * CIM_BN;
+  const int tiles_x = (p.Wout + CI_P - 1) / CI_P, tiles_y = (p.Hout + CI_P - 1) / CI_P, tiles_img = tiles_x * tiles_y;
+  const int ntiles = tiles_img * p.Z;
+  const int n0 = blockIdx.y * CIM_BN;
   const int Cout = p.Cout;
-  const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
-  for (int i = tid; i < CI_T * CI_T * 3; i += CIM_NT) {
-    const int c = i % 3, pix = i / 3, iy = pix / CI_T, ix = pix - iy * CI_T;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-    halo[iy * CI_PITCH + ix * 3 + c] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? a0[((long long)gy * p.Win + gx) * p.lda0 + c] : 0.f;
-  }
-  // ---- B fragments: lane = (column c16 of a 16-channel block, k group kq): w[k = 8 kq + j][n] * 2^10, two-term split ----
+  // ---- B fragments (once per workgroup, kept in LDS: 16 KB): lane = (column c16 of a 16-channel block, k group kq):
+  // w[k = 8 kq + j][n] * 2^10, two-term split; the waves of wave row 0 build the two column halves, every wave reads its half per tile
+  __shared__ __attribute__((aligned(16))) cih8 bfrag[2 * 4 * 2 * 64];         // [wn][tn][hi | lo][lane]
   const int r16 = lane & 15, kq = lane >> 4;
-  cih8 bh[4], bl[4];
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int n = n0 + wn * 64 + tn * 16 + r16;
-    float wv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 8 * kq + j;
-      wv[j] = (k < 27 && n < Cout) ? p.w[(long long)k * p.ldb + n] * 1024.f : 0.f;
-    }
-    ci_split8(wv, bh[tn], bl[tn]);
-  }
-  __syncthreads();
-  // ---- A fragments: row r16 of row block tm = patch pixel (py = wm * 4 + tm, px = r16); k = ky * 9 + (kx * 3 + ci) ----
-  cif4 acc[4][4];
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = cif4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int py = wm * 4 + tm;
-    float av[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 8 * kq + j, ky = k / 9, r = k - ky * 9;           // (k >= 27: ky = 3, never read)
-      av[j] = (k < 27) ? halo[(py + ky) * CI_PITCH + r16 * 3 + r] : 0.f;
-    }
-    cih8 ah, al;
-    ci_split8(av, ah, al);
+  if (wm == 0) {
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
+      const int n = n0 + wn * 64 + tn * 16 + r16;
+      const int nn = n < Cout ? n : Cout - 1;
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {   // unconditional loads from clamped addresses, zeroed by a select (no divergent branches)
+        const int k = 8 * kq + j;
+        const float v = p.w[(long long)(k < 27 ? k : 26) * p.ldb + nn] * 1024.f;
+        wv[j] = (k < 27 && n < Cout) ? v : 0.f;
+      }
+      cih8 h, l;
+      ci_split8(wv, h, l);
+      bfrag[((wn * 4 + tn) * 2 + 0) * 64 + lane] = h;
+      bfrag[((wn * 4 + tn) * 2 + 1) * 64 + lane] = l;
     }
   }
-  // ---- epilogue: the K32 main tile's (conv_f16x3.hip): C/D layout col = lane & 15 (channel), rows 4 (lane >> 4) + r (pixels) ->
-  // wave-private slab -> float4 = four consecutive channels of one pixel ----
-  float* const ep = slabs + wave * (16 * CIM_EP);
-  const int g = lane >> 4, c4 = lane & 15, prow = lane >> 4;      // 16 channel quads x 4 pixel rows per pass, 4 passes per row block
-  const int nq = n0 + wn * 64 + c4 * 4;
-  const bool nok = nq < Cout;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + nq);
-  float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
-  const bool want_stats = (p.stats != nullptr);
-  const bool full = (n0 + CIM_BN <= Cout) && (oy0 + CI_P <= p.Hout) && (ox0 + CI_P <= p.Wout);
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  constexpr float ALPHA = 1.0f / 1024.f;
-  auto stat4 = [&](const float4& v) {
-    s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
-    s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
-    s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
-    s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+  // element j of a lane's k group: halo[(py + ky) * PITCH + px * 3 + r] with k = 8 kq + j = ky * 9 + r; k >= 27 (k group 3, j >= 3)
+  // reads slot ZERO_SLOT (the unused pad word 54 of halo row 0, kept 0)
+  constexpr int ZERO_SLOT = 54;
+  if (tid == 0) halo[ZERO_SLOT] = 0.f;
+  // halo elements of this thread: i = tid, tid + 512 (< 18 * 18 * 3 = 972); the index arithmetic starts from a laundered thread id
+  // each time (hipcc otherwise keeps every derived offset alive across the matrix step and the epilogue and spills)
+  constexpr int NH = (CI_T * CI_T * 3 + CIM_NT - 1) / CIM_NT;   // 2
+  float hv[NH];
+  auto load_halo = [&](int t) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int zo = t / tiles_img, tt = t - zo * tiles_img, ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {   // unconditional load from a clamped address, zeroed by a select
+      const int i = t_ + e * CIM_NT;
+      const int c = i % 3, pix = i / 3, iy = pix / CI_T, ix = pix - iy * CI_T;
+      const int gy = ty * CI_P + iy - 1, gx = tx * CI_P + ix - 1;
+      const bool ok = i < CI_T * CI_T * 3 && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+      const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+      const float v = a0[((long long)cy * p.Win + cx) * p.lda0 + c];
+      hv[e] = ok ? v : 0.f;
+    }
   };
+  auto write_halo = [&]() {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
+    for (int e = 0; e < NH; ++e) {
+      const int i = t_ + e * CIM_NT;
+      const int c = i % 3, pix = i / 3, iy = pix / CI_T, ix = pix - iy * CI_T;
+      if (i < CI_T * CI_T * 3) halo[iy * CI_PITCH + ix * 3 + c] = hv[e];
+    }
+  };
+  float* const ep = slabs + wave * (16 * CIM_EP);
+  const bool want_stats = (p.stats != nullptr);
+  constexpr float ALPHA = 1.0f / 1024.f;
+
+  int t = blockIdx.x;
+  if (t < ntiles) load_halo(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int zo = t / tiles_img, tt = t - zo * tiles_img, ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int oy0 = ty * CI_P, ox0 = tx * CI_P;
+    write_halo();                                    // (the previous tile's fragment gathers finished before its barrier B)
+    __syncthreads();                                 // barrier A: halo(t) visible; `red` of the previous tile consumed
+    if (t + (int)gridDim.x < ntiles) load_halo(t + gridDim.x);   // in flight under the matrix step and the epilogue
+    // ---- A fragments: row r16 of row block tm = patch pixel (py = wm * 4 + tm, px = r16); k = ky * 9 + (kx * 3 + ci) ----
+    int aoff[8];
+    {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int ar = l_ & 15, akq = l_ >> 4;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ep[(4 * g + r) * CIM_EP + tn * 16 + r16] = acc[tm][tn][r] * ALPHA;
-    asm volatile("" ::: "memory");
-    const int oy = oy0 + wm * 4 + tm;
-    if (full) {   // straight-line stores (no per-element predicate: hipcc counts vmcnt instead of draining it before every store)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = prow + 4 * i;
-        const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
-        const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
-        *reinterpret_cast<float4*>(outz + ((long long)oy * p.Wout + ox0 + m) * p.ldo + nq) = v;
-        if (want_stats) stat4(v);
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * akq + j, ky = k / 9, r = k - ky * 9;
+        aoff[j] = (k < 27) ? ky * CI_PITCH + ar * 3 + r : -1;
       }
-    } else {
+    }
+    cif4 acc[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = prow + 4 * i;
-        const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
-        const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
-        if (nok && oy < p.Hout && ox0 + m < p.Wout) {
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = cif4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int py = wm * 4 + tm;
+      float av[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = halo[aoff[j] >= 0 ? py * CI_PITCH + aoff[j] : ZERO_SLOT];
+      cih8 ah, al;
+      ci_split8(av, ah, al);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const cih8 bh = bfrag[((wn * 4 + tn) * 2 + 0) * 64 + lane], bl = bfrag[((wn * 4 + tn) * 2 + 1) * 64 + lane];
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[tm][tn], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                 // barrier B: every wave has read halo(t); the next write_halo may overwrite it
+    // ---- epilogue: the K32 main tile's (conv_f16x3.hip): C/D layout col = lane & 15 (channel), rows 4 (lane >> 4) + r (pixels) ->
+    // wave-private slab -> float4 = four consecutive channels of one pixel ----
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    const int g = el >> 4, er16 = el & 15, c4 = el & 15, prow = el >> 4;   // 16 channel quads x 4 pixel rows per pass, 4 passes per row block
+    const int nq = n0 + wn * 64 + c4 * 4;
+    const bool nok = nq < Cout;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && nok) bv = *reinterpret_cast<const float4*>(p.bias + nq);
+    float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
+    const bool full = (n0 + CIM_BN <= Cout) && (oy0 + CI_P <= p.Hout) && (ox0 + CI_P <= p.Wout);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    auto stat4 = [&](const float4& v) {
+      s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x;
+      s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+      s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z;
+      s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+    };
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(4 * g + r) * CIM_EP + tn * 16 + er16] = acc[tm][tn][r] * ALPHA;
+      asm volatile("" ::: "memory");
+      const int oy = oy0 + wm * 4 + tm;
+      if (full) {   // straight-line stores (no per-element predicate: hipcc counts vmcnt instead of draining it before every store)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = prow + 4 * i;
+          const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
+          const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
           *reinterpret_cast<float4*>(outz + ((long long)oy * p.Wout + ox0 + m) * p.ldo + nq) = v;
           if (want_stats) stat4(v);
         }
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-  if (want_stats) {   // fixed order: in-lane -> the four lanes (g) that hold a channel quad -> the wave rows through LDS
+      } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16); s2[j] += __shfl_xor(s2[j], 16);
-      s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
+        for (int i = 0; i < 4; ++i) {
+          const int m = prow + 4 * i;
+          const float4 a = *reinterpret_cast<const float4*>(ep + m * CIM_EP + c4 * 4);
+          const float4 v = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+          if (nok && oy < p.Hout && ox0 + m < p.Wout) {
+            *reinterpret_cast<float4*>(outz + ((long long)oy * p.Wout + ox0 + m) * p.ldo + nq) = v;
+            if (want_stats) stat4(v);
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
     }
-    if (lane < 16) {
+    if (want_stats) {   // fixed order: in-lane -> the four lanes (g) that hold a channel quad -> the wave rows through LDS
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double* d = red + ((size_t)wm * CIM_BN + wn * 64 + c4 * 4 + j) * 2;
-        d[0] = s1[j];
-        d[1] = s2[j];
+        s1[j] += __shfl_xor(s1[j], 16); s2[j] += __shfl_xor(s2[j], 16);
+        s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
       }
-    }
-    __syncthreads();
-    for (int c = tid; c < CIM_BN; c += CIM_NT) {
-      if (n0 + c < Cout) {
-        double a = 0.0, b = 0.0;
+      if (el < 16) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          a += red[((size_t)w * CIM_BN + c) * 2];
-          b += red[((size_t)w * CIM_BN + c) * 2 + 1];
+        for (int j = 0; j < 4; ++j) {
+          double* d = red + ((size_t)wm * CIM_BN + wn * 64 + c4 * 4 + j) * 2;
+          d[0] = s1[j];
+          d[1] = s2[j];
         }
-        double* dst = p.stats + (((size_t)zo * gridDim.x + blockIdx.x) * Cout + n0 + c) * 2;
-        dst[0] = a;
-        dst[1] = b;
+      }
+      __syncthreads();
+      for (int c = tid; c < CIM_BN; c += CIM_NT) {
+        if (n0 + c < Cout) {
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            a += red[((size_t)w * CIM_BN + c) * 2];
+            b += red[((size_t)w * CIM_BN + c) * 2 + 1];
+          }
+          double* dst = p.stats + (((size_t)zo * tiles_img + tt) * Cout + n0 + c) * 2;   // rows = 16 x 16 patches per image
+          dst[0] = a;
+          dst[1] = b;
+        }
       }
     }
   }
@@ -301,7 +362,11 @@ int conv_in_stat_blocks(const GemmArgs& a) { return ((a.Hout + CI_P - 1) / CI_P)
 hipError_t launch_conv_in(const GemmArgs& a, hipStream_t s) {
   if (!conv_in_supported(a)) return hipErrorInvalidValue;
   if (conv_in_mfma_enabled()) {
-    hipLaunchKernelGGL(conv_in_mfma_kernel, dim3(conv_in_stat_blocks(a), (a.Cout + CIM_BN - 1) / CIM_BN, a.Z), dim3(CIM_NT), 0, s, a);
+    // persistent: two resident workgroups per CU and N block walk the (image, patch) tiles
+    const long long tiles = (long long)conv_in_stat_blocks(a) * a.Z;
+    const int ny = (a.Cout + CIM_BN - 1) / CIM_BN;
+    const int gx = (int)(tiles < 512 / ny ? tiles : 512 / ny);
+    hipLaunchKernelGGL(conv_in_mfma_kernel, dim3(gx, ny, 1), dim3(CIM_NT), 0, s, a);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(conv_in_kernel, dim3(conv_in_stat_blocks(a), 1, a.Z), dim3(CI_NT), 0, s, a);
