@@ -90,19 +90,24 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("ASYRP_LIBRARY") == "bench":
+        # explicit opt-in for A/B runs: the profiling build honours the ASYRP_* kernel switches, the product library reads none
+        path = BENCH_LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the Asyrp HIP engine has no CPU/PyTorch fallback. "
+            f"{path} not found: the Asyrp HIP engine has no CPU/PyTorch fallback. "
             "Build it with `python -m asyrp_official_amd.build` (needs hipcc, targets gfx950).")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args
     if lib.asyrp_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"{LIB_PATH} implements ABI v{lib.asyrp_abi_version()}, this package binds v{ABI_VERSION}: "
+        raise RuntimeError(f"{path} implements ABI v{lib.asyrp_abi_version()}, this package binds v{ABI_VERSION}: "
                            "rebuild with `python -m asyrp_official_amd.build`")
     _lib = lib
+    lib._asyrp_path = path
     return lib
 
 

@@ -1495,7 +1495,7 @@ static bool is_vec(const GemmArgs& a) {
 
 // A/B switch of the XCD-aware tile map (ASYRP_XCD_MAP=0 disables it)
 bool xcd_map_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_XCD_MAP"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_XCD_MAP"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -1586,7 +1586,7 @@ static bool k32spk_ok(const GemmArgs& a) {
 }
 // A/B switch: ASYRP_MAIN_TILE=6 keeps the 32x32x16 organisation for the automatic choice
 static bool k32_preferred() {
-  static const bool on = [] { const char* e = getenv("ASYRP_MAIN_TILE"); return !(e && e[0] == '6'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_MAIN_TILE"); return !(e && e[0] == '6'); }();
   return on;
 }
 
@@ -1859,13 +1859,13 @@ bool splitk_unfused(const GemmArgs& a) { return splitk_quad(a) || (small_class_t
 // K ranges of the 16 x 16 layers: 2 on the 128-pixel form (two tiles per image), or (ASYRP_SPLITK16=4, experiment) 4 on the
 // 256-pixel main tile (one tile per image: twice the matrix work per weight slice and barrier)
 int splitk16_ranges() {
-  static const int n = [] { const char* e = getenv("ASYRP_SPLITK16"); return (e && e[0] == '4') ? 4 : 2; }();
+  static const int n = [] { const char* e = ab_env("ASYRP_SPLITK16"); return (e && e[0] == '4') ? 4 : 2; }();
   return n;
 }
 bool splitk16(const GemmArgs& a) {
-  static const bool on = [] { const char* e = getenv("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
+  static const bool on = [] { const char* e = ab_env("ASYRP_SPLITK16"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
   // ASYRP_SPLITK32=1 (experiment, off by default): the same for the 32 x 32 maps on the 256-pixel form (4 x Cout/128 workgroups per image)
-  static const bool on32 = [] { const char* e = getenv("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
+  static const bool on32 = [] { const char* e = ab_env("ASYRP_SPLITK32"); return e && e[0] == '1'; }();
   const bool m16 = a.Hout == 16 && a.Wout == 16 && a.Hin == 16 && a.Win == 16, m32 = on32 && a.Hout == 32 && a.Wout == 32 && a.Hin == 32 && a.Win == 32;
   // (k32_split_epilogue_ok: the K32 float4 epilogue's rule -- Cout % 4, aligned rows -- so that the factor, the tile and the kernel
   //  that is launched are decided by ONE predicate; with Cout = 6 at 16 x 16 the old rule promised a K32 split form that
@@ -1881,7 +1881,7 @@ int splitk_tile(const GemmArgs& a) {
   return XT_64x64;
 }
 bool splitk_quad(const GemmArgs& a) {
-  static const bool on = [] { const char* e = getenv("ASYRP_QUAD8"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
+  static const bool on = [] { const char* e = ab_env("ASYRP_QUAD8"); return !(e && e[0] == '0'); }();   // A/B switch, recorded by bench.py
   return on && nominal_z(a) > 2 && a.ks == 3 && a.stride == 1 && !a.ups && !a.s0 && a.Hout == 8 && a.Wout == 8 && a.Hin == 8 && a.Win == 8 && a.Cin >= 512 &&
          (a.Cin % 256) == 0 && a.a0_zo == 64LL * a.lda0 && (!a.a1 || a.a1_zo == 64LL * a.lda1);
 }

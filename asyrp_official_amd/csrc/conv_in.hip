@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs 
 
 // A/B switch: ASYRP_CONV_IN_MFMA=0 keeps the fp32 stencil (exact fp32 products, VALU-bound)
 static bool conv_in_mfma_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_CONV_IN_MFMA"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_CONV_IN_MFMA"); return !(e && e[0] == '0'); }();
   return on;
 }
 

@@ -245,7 +245,7 @@ bool conv_out_two_tiles() {
   // the 6-channel iDDPM head on two N tiles of this kernel (round 4: on by default -- with the loads two chunks ahead it measured
   // 55.5 vs 46.0 TFLOP/s on the AFHQ head (Cin = 128), +0.2 % on that edit, profiles/r04a_*); ASYRP_CONV_OUT6=0 puts the head back on
   // the implicit-GEMM tile
-  static const bool on = [] { const char* e = getenv("ASYRP_CONV_OUT6"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_CONV_OUT6"); return !(e && e[0] == '0'); }();
   return on;
 }
 bool conv_out_supported(const GemmArgs& a) {

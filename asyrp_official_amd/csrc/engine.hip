@@ -661,7 +661,7 @@ int run_gemm(Ctx& c, const GemmArgs& g) {
 // A/B switch of the polyphase form of the up-sampled 3x3 convolutions (ASYRP_POLYPHASE=0 keeps the 3x3 form over the virtual
 // up-sampling); like the other switches its value is recorded in bench.py's line
 static bool polyphase_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_POLYPHASE"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_POLYPHASE"); return !(e && e[0] == '0'); }();
   return on;
 }
 // 1x1 convolutions of the 16 x 16 feature maps (the attention blocks of every 256-pixel config) on the barrier-free kernel of gemm1x1.hip;
@@ -669,7 +669,7 @@ static bool polyphase_enabled() {
 // tiles, for A/B; =256: its 8-wave form); a function of the layer shape only.  Recorded in bench.py's line like the other switches.
 static int gemm1x1_tile() {
   static const int t = [] {
-    const char* e = getenv("ASYRP_GEMM1X1");
+    const char* e = ab_env("ASYRP_GEMM1X1");
     if (e && e[0] == '0') return 0;
     return (e && e[0] == '2') ? (int)XT_G1_256 : (int)XT_G1_128;
   }();
@@ -686,7 +686,7 @@ static void try_gemm1x1(Ctx& c, const std::string& wname, GemmArgs& g) {
 }
 // A/B switch of the dedicated first-convolution kernel (ASYRP_CONV_IN=0: the implicit-GEMM tile with scalar-gather staging)
 static bool conv_in_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_CONV_IN"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_CONV_IN"); return !(e && e[0] == '0'); }();
   return on;
 }
 // y = conv(act(x0|x1)) + bias (+chan_add) (+resid);  act = optional per-(image,channel) affine (+SiLU)
@@ -898,7 +898,7 @@ int tproj_gemm(Ctx& c, const float* temb_act) {
 // (the single-decoder steps keep the one-launch form).  ASYRP_SKIP_SHARE=0 disables it.
 struct SkipPlan { int dirty, nclean; };
 static bool skip_share_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_SKIP_SHARE"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_SKIP_SHARE"); return !(e && e[0] == '0'); }();
   return on;
 }
 static bool skip_plan(const Act& x0, const Act& x1, SkipPlan* pl) {
@@ -1075,7 +1075,7 @@ int attention_core(Ctx& c, const float* qkv, int C, int T, int heads, float scal
 // round-2 kernel (fp32 q|k|v, operands split in registers) for A/B; recorded in bench.py's line like the other switches.
 struct QkvPlanes { _Float16 *h = nullptr, *l = nullptr, *vth = nullptr, *vtl = nullptr; float* raw[4] = {nullptr, nullptr, nullptr, nullptr}; int ld16 = 0; };
 static bool attn_planes_enabled() {
-  static const bool on = [] { const char* e = getenv("ASYRP_ATTN"); return !(e && e[0] == 'o'); }();
+  static const bool on = [] { const char* e = ab_env("ASYRP_ATTN"); return !(e && e[0] == 'o'); }();
   return on;
 }
 void drop_planes(Ctx& c, QkvPlanes& pl) {

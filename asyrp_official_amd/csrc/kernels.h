@@ -2,8 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace asyrp {
+
+// A/B switches (ASYRP_MAIN_TILE, ASYRP_POLYPHASE, ASYRP_ATTN, ...).  The PRODUCT library reads no environment variable: every switch
+// is at its default there and the superseded kernels are reachable only as shape fallbacks.  The profiling library
+// (libasyrp_hip_bench.so, -DASYRP_BENCH_HOOKS; loaded instead of the product by ASYRP_LIBRARY=bench, which bench.py records in its
+// line) honours them, each read once per process.
+inline const char* ab_env(const char* name) {
+#ifdef ASYRP_BENCH_HOOKS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // One implicit-GEMM launch: out[z][m][n] = alpha * sum_k A[z][m][k] * B[(z)][k][n] (+bias +chan_add +resid)
 //   A = activations, NHWC, up to two channel-concatenated sources, optional per-(image,channel)

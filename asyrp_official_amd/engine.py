@@ -283,8 +283,11 @@ class Engine:
             return "attention", "asyrp::attn_f16x3_kernel (T=%d)" % (v - 200000)
         if fam == 3:
             return "f16x3", "asyrp::conv_out_kernel (Cout=%d)" % (v - 300000)
-        if fam == 4:
-            return "f16x3", "asyrp::conv_in_kernel (Cout=%d)" % (v - 400000)
+        if fam == 4:   # conv_in.hip: the one-K-step MFMA form (round 5, default) or the fp32 stencil (ASYRP_CONV_IN_MFMA=0)
+            import os
+            stencil = os.environ.get("ASYRP_LIBRARY") == "bench" and os.environ.get("ASYRP_CONV_IN_MFMA", "1")[:1] == "0"
+            k = "conv_in_kernel" if stencil else "conv_in_mfma_kernel"
+            return "f16x3", "asyrp::%s (Cout=%d)" % (k, v - 400000)
         if fam == 1:
             tile = {1: (4, 1, 2, 4), 2: (2, 2, 2, 2), 3: (2, 2, 1, 2), 4: (2, 2, 1, 1), 5: (4, 1, 2, 2), 6: (4, 2, 2, 2),
                     12: (4, 1, 2, 1)}.get(tid, (0,) * 4)

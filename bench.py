@@ -190,7 +190,7 @@ def _self_launch(n):
 
 def paste_traffic(res, tpath, lib_path, dt, steps):
     """HBM traffic per kernel family into a result line.  PMC counters cannot be read inline; the committed rocprofv3 --pmc passes
-    of this command (scripts/gpu_traffic_families.sh -> profiles/traffic_families_<config>_b<B>_<math>.json) are reported per launch
+    of this command (scripts/gpu.sh traffic -> profiles/traffic_families_<config>_b<B>_<math>.json) are reported per launch
     -- but only when they were taken on the library that is loaded now (sha256 stamp): a stale measurement is refused, never pasted.
     dt = seconds of the timed region, steps = its step count (kernel_families carries each family's share of the region and its
     launches per step)."""
@@ -213,6 +213,9 @@ def paste_traffic(res, tpath, lib_path, dt, steps):
     for fm in res.get("kernel_families", []):
         key = fm["kernel"].split(" (")[0]
         ht = fams_t.get(key)
+        if "attn_planes_kernel (T=" in fm["kernel"]:   # the counter file has one row per key-tile count of the kernel (T = 256 -> 2, 64 -> 1)
+            T = int(fm["kernel"].split("(T=")[1].rstrip(")"))
+            ht = fams_t.get("asyrp::attn_planes_kernel<%d>" % ((T // 16 + 7) // 8)) or ht
         if ht and fm["launches_per_step"]:
             sec_per_launch = fm["share_of_step"] * dt / steps / fm["launches_per_step"]
             fm["counter_bytes_per_launch"] = ht["hbm_bytes_per_launch"]
@@ -468,7 +471,11 @@ def main():
                                         if world > 1 and backend == "nccl" else None),
                        # A/B switches read by the library from the environment: a non-default kernel choice can never be
                        # benchmarked silently
-                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16", "ASYRP_SPLITK32", "ASYRP_CONV_IN", "ASYRP_CONV_OUT6")},
+                       # (round 5: the PRODUCT library reads no environment; the switches act only when the profiling build is loaded
+                       #  in its place with ASYRP_LIBRARY=bench, and `library` says which one produced this line)
+                       "library": "profiling build (ASYRP_LIBRARY=bench: A/B switches honoured)" if os.environ.get("ASYRP_LIBRARY") == "bench" else "product",
+                       "switches": {k: os.environ.get(k, "default") for k in ("ASYRP_MAIN_TILE", "ASYRP_SKIP_SHARE", "ASYRP_XCD_MAP", "ASYRP_POLYPHASE", "ASYRP_ATTN", "ASYRP_QUAD8", "ASYRP_GEMM1X1", "ASYRP_SPLITK16", "ASYRP_SPLITK32", "ASYRP_CONV_IN", "ASYRP_CONV_IN_MFMA", "ASYRP_CONV_OUT6")}
+                       if os.environ.get("ASYRP_LIBRARY") == "bench" else "not read by the product library",
                        "conv_math": a.conv_math, "nominal_batch": a.nominal_batch or 32},
             "phase_ms_per_step": phases,
             # generation only (x_T given, e.g. --load_random_noise): derived from the per-step times above
@@ -523,7 +530,7 @@ def main():
         # HBM traffic per kernel family (see paste_traffic): only a measurement taken on THIS library build is reported
         if "roofline" in res:
             from asyrp_official_amd import _lib
-            paste_traffic(res, os.path.join(ROOT, "profiles", f"traffic_families_{a.config}_b{B}_{a.conv_math}.json"), _lib.LIB_PATH,
+            paste_traffic(res, os.path.join(ROOT, "profiles", f"traffic_families_{a.config}_b{B}_{a.conv_math}.json"), getattr(_lib.load(), "_asyrp_path", _lib.LIB_PATH),
                           dt, a.steps)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], cpu_chk = cpu_baseline(cpu_sd, betas, family, learn_sigma,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes of SQ / GRBM counters (scripts/gpu_pmc_families.sh) per kernel family of one whole edit:
+"""Summarise rocprofv3 --pmc passes of SQ / GRBM counters (scripts/gpu.sh pmc) per kernel family of one whole edit:
 mean launch duration under the profiler, effective clock, matrix-pipe busy fraction, split of the wave cycles.
 usage: pmc_summary.py <dir with pass*/> <library.so> <out.json>"""
 import collections
@@ -12,7 +12,53 @@ import sys
 from traffic_summary import family
 
 
+def k32_summary(root, out):
+    """scripts/gpu.sh pmc-k32: the main tile in its two instruction forms (16x16x32 = "k32", 32x32x16 = "w8") on one layer."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for d in glob.glob(f"{root}/*/"):
+        for f in glob.glob(d + "*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                agg["k32" if "k32" in r["Kernel_Name"] else "w8"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for f in glob.glob(d + "*kernel_trace.csv"):
+            for r in csv.DictReader(open(f)):
+                dur["k32" if "k32" in r["Kernel_Name"] else "w8"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    res = {}
+    for k in agg:
+        m = {c: sum(v) / len(v) for c, v in agg[k].items()}
+        ms = sum(dur[k]) / max(1, len(dur[k]))
+        m["mean_ms_under_profiler"] = ms
+        if "GRBM_GUI_ACTIVE" in m:
+            m["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e-3) / 1e9
+            m["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (m["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
+        res[k] = m
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+def calib_hbm_summary(root, out):
+    """scripts/gpu.sh calib-hbm: FETCH_SIZE / WRITE_SIZE of scripts/calib/hbm_counters.hip against its known byte counts."""
+    BYTES = 2 << 30
+    res = {"bytes_per_launch": BYTES}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob(f"{root}/calib_{c}/*counter_collection.csv")
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == c:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            kb = sum(v) / len(v)
+            res.setdefault(k, {})[c + "_KB"] = kb
+            res[k][c + "_reported_over_true"] = kb * 1024.0 / BYTES
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--k32":
+        return k32_summary(sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "--calib-hbm":
+        return calib_hbm_summary(sys.argv[2], sys.argv[3])
     root, lib, out = sys.argv[1:4]
     cnt = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     dur = collections.defaultdict(lambda: [0.0, 0])

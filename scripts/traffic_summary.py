@@ -27,6 +27,9 @@ def family(name):
     m = re.search(r"igemm_f32_kernel<asyrp::TileCfg<([\d, ]+)>", name)
     if m:
         return "asyrp::igemm_f32_kernel<asyrp::TileCfg<%s>>" % ", ".join(v.strip() for v in m.group(1).split(",")[:6])
+    m = re.search(r"attn_planes_kernel<(\d+)", name)   # one row per key-tile count (T = 256 -> 2, T = 64 -> 1): the two sites move different bytes
+    if m:
+        return "asyrp::attn_planes_kernel<%s>" % m.group(1)
     m = re.search(r"asyrp::(\w+)", name)
     return "asyrp::" + m.group(1) if m else name
 
@@ -55,7 +58,7 @@ def main():
                   "hbm_bytes_per_launch": 1024.0 * (2.0 * fk + 1.0 * wk)}
     res = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "workload": workload,
            "collection": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over every kernel "
-                         "(scripts/gpu_traffic_families.sh); bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE), scales calibrated in "
+                         "(scripts/gpu.sh traffic); bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE), scales calibrated in "
                          "profiles/r02zz_calib_hbm_counters.json",
            "families": dict(sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))}
     json.dump(res, open(out, "w"), indent=1)

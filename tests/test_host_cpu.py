@@ -394,3 +394,14 @@ def test_data_parallel_replication_fails_loudly():
         with pytest.raises(AsyrpDeviceError, match="one process per GPU"):
             m._replicate_for_data_parallel()
 
+
+def test_product_library_reads_no_environment_switch():
+    """Round 5 hygiene: every ASYRP_* kernel switch lives in the PROFILING build only; the product library has no
+    switch name in its image and does not import getenv, so a shell variable cannot change which kernels a product run executes."""
+    import subprocess
+    from asyrp_official_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"ASYRP_" not in blob, "an environment switch name is compiled into the product library"
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+
