@@ -676,7 +676,11 @@ static int gemm1x1_tile() {
   return t;
 }
 static void try_gemm1x1(Ctx& c, const std::string& wname, GemmArgs& g) {
-  if (!gemm1x1_tile() || g.ks != 1 || g.Hout * g.Wout != 256 || g.s0 || g.sk > 1 || !gemm1x1_ok(g)) return;
+  // 16 x 16 maps, and (round 5) 8 x 8 maps on the pair form of the 4-wave kernel: two images per workgroup instead of the 64 x 64
+  // implicit-GEMM tile that ran these layers (mid attention q|k|v / proj_out, the DeltaBlock's 1x1 convolutions) at 35 TFLOP/s
+  const int hw = g.Hout * g.Wout;
+  const bool pair8 = hw == 64 && gemm1x1_tile() == XT_G1_128 && (!g.pscale || g.Cin <= 1024);
+  if (!gemm1x1_tile() || g.ks != 1 || !(hw == 256 || pair8) || g.s0 || g.sk > 1 || !gemm1x1_ok(g)) return;
   auto it = c.e->xw.find(wname + "#g1");
   if (it == c.e->xw.end()) return;
   g.tile = gemm1x1_tile();

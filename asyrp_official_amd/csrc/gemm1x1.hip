@@ -105,7 +105,14 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
   G1_STAMP(0);
   if (p.xmap) wg = (wg & 7) * ((int)(gridDim.x * gridDim.y * gridDim.z) >> 3) + (wg >> 3);
   const int mb = wg % (int)gridDim.x, nbz = wg / (int)gridDim.x;
-  const int zo = nbz / (int)gridDim.y, n0 = (nbz % (int)gridDim.y) * BN, m0 = mb * BM;
+  const int zblk = nbz / (int)gridDim.y, n0 = (nbz % (int)gridDim.y) * BN, m0 = mb * BM;
+  // pair form (GemmArgs.g1_pair, WM = 2, 8 x 8 maps): wave row wm = image 2 zblk + wm, rows 0..63 of that image; an absent second
+  // image (odd batch) is computed on the last image's data and not stored
+  const bool pair = (WM == 2) && p.g1_pair;
+  const int zraw = pair ? zblk * 2 + wm : zblk;
+  const bool zvalid = zraw < p.Z;
+  const int zo = zvalid ? zraw : p.Z - 1;
+  const int mw = pair ? 0 : m0 + wm * 64;              // first row of this wave within its image
   const int HWo = p.Hout * p.Wout, Cout = p.Cout, c0s = p.c0;
   const int nsteps = p.Cin >> 5, lda0 = p.lda0, lda1 = p.lda1;
   const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
   // this lane's pixel in each of the wave's four 16-row blocks (clamped: rows past the image are computed and discarded)
   int arow[4];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) arow[tm] = min(m0 + wm * 64 + tm * 16 + r16, HWo - 1);
+  for (int tm = 0; tm < 4; ++tm) arow[tm] = min(mw + tm * 16 + r16, HWo - 1);
   // B: the wave's four 16-channel tiles; tile index clamped to the last existing one (its missing rows are zero in the image)
   const int ntiles = (Cout + 15) >> 4;
   long long boff[4];
@@ -156,16 +163,26 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
 #pragma unroll
   for (int u = 0; u < D; ++u) load_step(min(u, nsteps - 1), u);
   __builtin_amdgcn_sched_barrier(0);
+  const int cq = p.Cin >> 2;
+  const int spo = pair ? wm * 2 * cq : 0;             // this wave's scale | shift rows in LDS (pair form: one pair of rows per image)
   if (PRO) {   // the only barrier of the kernel: scale/shift rows of this image -> LDS while the first steps are in flight
     const int nq = p.Cin >> 2;
-    for (int i = tid; i < nq; i += NT) {
-      sps[i] = *reinterpret_cast<const float4*>(ps + 4 * i);
-      sps[nq + i] = *reinterpret_cast<const float4*>(psh + 4 * i);
+    if (pair) {   // both images' rows (launcher: Cin <= G1_MAXC / 2)
+      for (int i = tid; i < 2 * nq; i += NT) {
+        const int im = i / nq, q = i - im * nq;
+        const long long zi = min(zblk * 2 + im, p.Z - 1);
+        sps[im * 2 * nq + q] = *reinterpret_cast<const float4*>(p.pscale + zi * ldps + 4 * q);
+        sps[im * 2 * nq + nq + q] = *reinterpret_cast<const float4*>(p.pshift + zi * ldps + 4 * q);
+      }
+    } else {
+      for (int i = tid; i < nq; i += NT) {
+        sps[i] = *reinterpret_cast<const float4*>(ps + 4 * i);
+        sps[nq + i] = *reinterpret_cast<const float4*>(psh + 4 * i);
+      }
     }
     __syncthreads();
   }
   G1_STAMP(1);
-  const int cq = p.Cin >> 2;
   for (int s0 = 0; s0 < nsteps; s0 += D) {           // nsteps % D == 0 (launcher: Cin % 64 == 0)
 #pragma unroll
     for (int u = 0; u < D; ++u) {
@@ -173,7 +190,7 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
       float sc[8], sh[8];
       if (PRO) {
         const int q = s * 8 + g * 2;
-        const float4 c0 = sps[q], c1 = sps[q + 1], d0 = sps[cq + q], d1 = sps[cq + q + 1];
+        const float4 c0 = sps[spo + q], c1 = sps[spo + q + 1], d0 = sps[spo + cq + q], d1 = sps[spo + cq + q + 1];
         sc[0] = c0.x; sc[1] = c0.y; sc[2] = c0.z; sc[3] = c0.w; sc[4] = c1.x; sc[5] = c1.y; sc[6] = c1.z; sc[7] = c1.w;
         sh[0] = d0.x; sh[1] = d0.y; sh[2] = d0.z; sh[3] = d0.w; sh[4] = d1.x; sh[5] = d1.y; sh[6] = d1.z; sh[7] = d1.w;
       }
@@ -216,14 +233,14 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       const int n = n0 + wn * 64 + tn * 16 + r16;
-      if (n >= Cout) continue;
+      if (n >= Cout || !zvalid) continue;
       const float add = (p.bias ? p.bias[n] : 0.f) + (cadd ? cadd[n] : 0.f);
       const int nm = n % p.v_mod;
       const bool isv = nm >= p.v_off;
       const int vc = (n / p.v_mod) * p.v_dh + nm - p.v_off;
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
-        const int pix = m0 + wm * 64 + tm * 16 + 4 * g;
+        const int pix = mw + tm * 16 + 4 * g;
         h4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -254,7 +271,7 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
   }
   float* __restrict__ outz = p.out + (long long)zo * p.o_zo;
   const bool want_stats = (p.stats != nullptr);
-  const bool full_tile = (n0 + BN <= Cout) && (m0 + BM <= HWo);
+  const bool full_tile = (n0 + BN <= Cout) && (pair ? (zvalid && HWo == 64) : (m0 + BM <= HWo));   // (wave-uniform)
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int n = n0 + wn * 64 + tn * 16 + r16;
@@ -270,14 +287,14 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
+          const int pix = mw + tm * 16 + 4 * g + r;
           rv[tm][r] = rz ? rz[(long long)pix * p.ldr + n] : 0.f;
         }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
+          const int pix = mw + tm * 16 + 4 * g + r;
           const float v = (acc[tm][tn][r] * p.alpha + add) + rv[tm][r];
           outz[(long long)pix * p.ldo + n] = v;
           if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
@@ -287,8 +304,8 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
       for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pix = m0 + wm * 64 + tm * 16 + 4 * g + r;
-          if (nok && pix < HWo) {
+          const int pix = mw + tm * 16 + 4 * g + r;
+          if (nok && pix < HWo && zvalid) {
             const float v = (acc[tm][tn][r] * p.alpha + add) + (rz ? rz[(long long)pix * p.ldr + n] : 0.f);
             outz[(long long)pix * p.ldo + n] = v;
             if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
@@ -309,14 +326,25 @@ __global__ void __launch_bounds__(WM * 128, 4 / WM) gemm1x1_k32_kernel(const Gem
   if (want_stats) {
     __syncthreads();
     for (int c = tid; c < BN; c += NT) {
-      if (n0 + c < Cout) {
+      if (n0 + c >= Cout) continue;
+      if (pair) {   // a wave row is an image: its row of sums is that image's (single) statistics row
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          const int zi = zblk * 2 + w;
+          if (zi < p.Z) {
+            double* dst = p.stats + ((size_t)zi * Cout + n0 + c) * 2;
+            dst[0] = red[((size_t)w * BN + c) * 2];
+            dst[1] = red[((size_t)w * BN + c) * 2 + 1];
+          }
+        }
+      } else {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int w = 0; w < WM; ++w) {
           s1 += red[((size_t)w * BN + c) * 2];
           s2 += red[((size_t)w * BN + c) * 2 + 1];
         }
-        double* dst = p.stats + (((size_t)zo * gridDim.x + mb) * Cout + n0 + c) * 2;
+        double* dst = p.stats + (((size_t)zblk * gridDim.x + mb) * Cout + n0 + c) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -336,8 +364,11 @@ bool gemm1x1_ok(const GemmArgs& a) {
 
 template <int NP, int WM>
 static hipError_t launch_g1(const GemmArgs& a, hipStream_t s) {
-  dim3 grid((a.Hout * a.Wout + WM * 64 - 1) / (WM * 64), (a.Cout + 127) / 128, a.Z), block(WM * 128);
+  // 8 x 8 maps on the 4-wave form: two images per workgroup (GemmArgs.g1_pair); needs both images' scale/shift rows in LDS
+  const bool pair = (WM == 2) && a.Hout * a.Wout == 64 && (!a.pscale || a.Cin <= G1_MAXC / 2);
+  dim3 grid(pair ? 1 : (a.Hout * a.Wout + WM * 64 - 1) / (WM * 64), (a.Cout + 127) / 128, pair ? (a.Z + 1) / 2 : a.Z), block(WM * 128);
   GemmArgs ax = a;
+  ax.g1_pair = pair ? 1 : 0;
   ax.xmap = (xcd_map_enabled() && ((long long)grid.x * grid.y * grid.z) % 8 == 0) ? 1 : 0;
   if (a.pscale) hipLaunchKernelGGL((gemm1x1_k32_kernel<NP, WM, true>), grid, block, 0, s, ax);
   else hipLaunchKernelGGL((gemm1x1_k32_kernel<NP, WM, false>), grid, block, 0, s, ax);

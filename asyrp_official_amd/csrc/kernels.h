@@ -79,6 +79,10 @@ struct GemmArgs {
   // profiling library only (K32 ablation instantiation): stag == 3 delays the second workgroup to arrive on a CU by stag_ticks
   // (100 MHz) once; the arrival counters sit behind the stamps in dbg.  0 in the product.
   int stag, stag_ticks;
+  // gemm1x1.hip, XT_G1_128 on 8 x 8 maps (round 5; set by launch_gemm1x1): the workgroup's two wave rows take two IMAGES (64 pixels
+  // each) instead of two 64-pixel halves of one image; gridDim.z = ceil(Z / 2).  Per image the instructions and their order are
+  // those of the one-image form, so an image's bits do not depend on its partner.
+  int g1_pair;
 };
 
 enum { MATH_F16X3 = 0, MATH_F32 = 1 };

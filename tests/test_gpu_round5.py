@@ -183,3 +183,62 @@ def test_conv3x3_at_16x16_with_cout_not_a_multiple_of_4(Cout):
     gn = (1 + 0.1 * hash_uniform("r5.c16.g", (Cin,)), 0.1 * hash_uniform("r5.c16.be", (Cin,)))
     got = hip_conv(x, w, b, gn=gn, silu=True)
     assert_close(got, ref_conv(x, w, b, gn=gn, silu=True), what=f"conv3x3 16x16 Cin=256 Cout={Cout}", **TIGHT)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("B,C0,C1,Cout,pro,res", [(3, 512, 0, 512, True, True), (2, 512, 0, 1536, True, False), (1, 512, 0, 512, False, True),
+                                                   (5, 256, 256, 200, True, True), (4, 1024, 0, 512, True, False)])
+def test_1x1_kernel_pair_form_on_8x8_maps(B, C0, C1, Cout, pro, res, math):
+    """gemm1x1.hip on 8 x 8 maps (round 5): the two wave rows of a workgroup take two IMAGES -- mid-attention q|k|v / proj_out and
+    the DeltaBlock's 1x1 convolutions, which ran on the 64 x 64 implicit-GEMM tile at 35 TFLOP/s.  Odd batches (the last workgroup's
+    second image is absent), a concat input, a ragged N tile, per-image GroupNorm rows / channel vectors / residuals, against torch fp32;
+    every image alone == the image in the batch bit for bit (whatever its partner and its wave row)."""
+    from test_gpu_ops import TIGHT, hip_conv, ref_conv
+    x0 = hash_normal(f"g1p.x0.{B}.{C0}", (B, C0, 8, 8))
+    x1 = hash_normal(f"g1p.x1.{B}.{C1}", (B, C1, 8, 8)) if C1 else None
+    Cin = C0 + C1
+    w = hash_uniform(f"g1p.w.{Cin}.{Cout}", (Cout, Cin, 1, 1), -1, 1) / Cin ** 0.5
+    b = 0.1 * hash_uniform(f"g1p.b.{Cout}", (Cout,))
+    gn = (1 + 0.1 * hash_uniform(f"g1p.g.{Cin}", (Cin,)), 0.1 * hash_uniform(f"g1p.be.{Cin}", (Cin,))) if pro else None
+    r = hash_normal(f"g1p.r.{B}.{Cout}", (B, Cout, 8, 8)) if res else None
+    ca = hash_normal(f"g1p.ca.{B}.{Cout}", (B, Cout))
+    kw = dict(x1=x1, gn=gn, silu=pro and Cout != 1536, residual=r, chan_add=ca)
+    got = hip_conv(x0, w, b, math=math, tile=16, **kw)
+    want = ref_conv(x0, w, b, **kw)
+    if math == "f16x3":
+        assert_close(got, want, what="1x1 kernel, pair form", **TIGHT)
+        auto = hip_conv(x0, w, b, math=math, **kw)          # (the op hook's automatic tile: the implicit-GEMM tile; the ENGINE routes these layers to the pair form)
+        for i in range(B):
+            alone = hip_conv(x0[i:i + 1], w, b, x1=None if x1 is None else x1[i:i + 1], gn=gn, silu=kw["silu"],
+                             residual=None if r is None else r[i:i + 1], chan_add=ca[i:i + 1], math=math, tile=16)
+            assert torch.equal(alone[0], got[i]), f"pair form: image {i} depends on the batch"
+        assert_close(auto, want, what="1x1 at 8x8, automatic choice", **TIGHT)
+    else:
+        err = float((got - want).abs().max())
+        assert 1e-6 * float(want.abs().max()) < err <= 4e-3 * float(want.abs().max())
+
+
+def test_1x1_kernel_pair_form_statistics():
+    """GroupNorm partials of the pair form: one statistics row per image, written from the image's own wave row (odd batch)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from asyrp_official_amd import _lib
+    lib = _lib.load()
+    _p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    B, Cin, Cout, H, W, offset = 3, 512, 512, 8, 8, 7.0
+    x = hash_normal("g1pst.x", (B, Cin, H, W))
+    w = hash_uniform("g1pst.w", (Cout, Cin, 1, 1), -1, 1) / Cin ** 0.5
+    b = 0.1 * hash_uniform("g1pst.b", (Cout,)) + offset
+    gam, bet = 1 + 0.1 * hash_uniform("g1pst.g", (Cout,)), 0.1 * hash_uniform("g1pst.be", (Cout,))
+    d = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = map(d, (x, w, b, gam, bet))
+    y = torch.empty((B, Cout, H, W), device="cuda")
+    sc, sh = torch.empty((B, Cout), device="cuda"), torch.empty((B, Cout), device="cuda")
+    _lib.check(lib.asyrp_op_conv2d_stats(0, _p(xd), Cin, B, H, W, _p(wd), _p(bd), Cout, 1, 16, _p(gd), _p(bed), 1e-6,
+                                         _p(y), _p(sc), _p(sh), None))
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x, w, b)
+    assert_close(y.cpu(), want_y, what="conv", rtol=1e-4, atol=2e-5 * offset)
+    got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
+    assert_close(got_gn, want_gn, what="fused GN, pair form", rtol=1e-3, atol=1e-4)
