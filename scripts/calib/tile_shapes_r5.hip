@@ -63,17 +63,19 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
   }
 }
 
-constexpr int BN = 128, B_BYTES = BN * 64;
 constexpr long long TILE_ACT_FLOATS = 324LL * 128;   // one tile's 18 x 18 halo x 128 channels (fp32), its own region of the buffer
 
 // WINO = false: the product's main tile.  WINO = true: the F(2,3) tiling described above.
-template <bool WINO, int MINW, int STAGE>
-__global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Float16* __restrict__ wg, size_t wbytes, const float* __restrict__ act,
+// BIG (direct form only): a 256-pixel x 256-CHANNEL tile, 16 waves as 4 x 4, one workgroup per CU (107 KB of LDS): the staged halo
+// feeds twice the output channels (the layers with Cout >= 256: 18 % of the main tile's flops)
+template <bool WINO, int MINW, int STAGE, bool BIG = false>
+__global__ void __launch_bounds__((WINO || BIG) ? 1024 : 512, MINW) tile_kernel(const _Float16* __restrict__ wg, size_t wbytes, const float* __restrict__ act,
                                                                       size_t act_floats, const float* __restrict__ scsh, float* __restrict__ out,
                                                                       int nch /* 16-channel chunks */) {
   constexpr int stage = STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = WINO ? 16 : 8, NT = NW * 64;
+  constexpr int BN = BIG ? 256 : 128, B_BYTES = BN * 64;
+  constexpr int NW = (WINO || BIG) ? 16 : 8, NT = NW * 64;
   constexpr int NSLICE = WINO ? 8 : 2;                        // 8-KB slices per K = 32 step
   constexpr int SLOT = NSLICE * B_BYTES, NSLOT = WINO ? 1 : 2;
   constexpr int PLANE = WINO ? 144 : 336;                     // unit-plane pitch in pixels
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
   char* const As = smem + NSLOT * SLOT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int plane = WINO ? wave >> 2 : 0, wm = WINO ? (wave >> 1) & 1 : wave >> 1, wn = wave & 1;
+  const int plane = WINO ? wave >> 2 : 0, wm = WINO ? (wave >> 1) & 1 : (BIG ? wave >> 2 : wave >> 1), wn = BIG ? wave & 3 : wave & 1;
   const long long tile = blockIdx.x;
   const float* __restrict__ atile = act + (size_t)((tile * TILE_ACT_FLOATS) % (long long)(act_floats - TILE_ACT_FLOATS));
   const char* wsrc = reinterpret_cast<const char*>(wg);
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
   }
 
   // ---- epilogue: 128 KB of fp32 per tile ----
-  float* const otile = out + (size_t)tile * 256 * 128;
+  float* const otile = out + (size_t)tile * 256 * BN;
   constexpr int EP = 68;
   float* const slab = reinterpret_cast<float*>(smem) + wave * (16 * EP);
   const int g = lane >> 4, er16 = lane & 15, c4 = lane & 15, prow = lane >> 4;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(WINO ? 1024 : 512, MINW) tile_kernel(const _Fl
       for (int i = 0; i < 4; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(slab + (prow + 4 * i) * EP + c4 * 4);
         const int pix = (wm * 4 + tm) * 16 + prow + 4 * i;
-        *reinterpret_cast<float4*>(otile + pix * 128 + wn * 64 + c4 * 4) = v;
+        *reinterpret_cast<float4*>(otile + pix * BN + wn * 64 + c4 * 4) = v;
       }
       asm volatile("" ::: "memory");
     }
@@ -396,17 +398,18 @@ static void read_clk_power(double* mhz, double* watts) {   // the busiest card o
   }
 }
 
-template <bool WINO, int MINW, int STAGE>
+template <bool WINO, int MINW, int STAGE, bool BIG = false>
 static void run(const char* name, int nch, const _Float16* w, size_t wbytes, const float* act, size_t act_floats, const float* scsh, float* out) {
+  constexpr int B_BYTES = (BIG ? 256 : 128) * 64;
   constexpr int NSLOT = WINO ? 1 : 2, SLOT = (WINO ? 8 : 2) * B_BYTES, A_BYTES = (WINO ? 4 * 4 * 144 : 4 * 336) * 16;
   const size_t smem = NSLOT * (size_t)SLOT + 2 * (size_t)A_BYTES;
   constexpr int stage = STAGE;
-  auto k = tile_kernel<WINO, MINW, STAGE>;
+  auto k = tile_kernel<WINO, MINW, STAGE, BIG>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
     printf("%-58s: LDS %zu B refused\n", name, smem);
     return;
   }
-  const int tiles = 8192, NT = WINO ? 1024 : 512;
+  const int tiles = BIG ? 4096 : 8192, NT = (WINO || BIG) ? 1024 : 512;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), smem, 0, w, wbytes, act, act_floats, scsh, out, nch);
@@ -432,8 +435,8 @@ static void run(const char* name, int nch, const _Float16* w, size_t wbytes, con
   (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / launches;
-  const double tf = (double)tiles * 256 * 128 * (nch * 16.0) * 9 * 2 / (us * 1e-6) / 1e12;   // the layer's direct-convolution flops
-  printf("%-58s %4d->128 %s: %8.1f us per launch = %6.1f TFLOP/s direct-equivalent; LDS %3zu KB; sclk %5.0f MHz %5.0f W (n=%d)\n", name, nch * 16,
+  const double tf = (double)tiles * 256 * (BIG ? 256 : 128) * (nch * 16.0) * 9 * 2 / (us * 1e-6) / 1e12;   // the layer's direct-convolution flops
+  printf("%-58s %4d->%3d %s: %8.1f us per launch = %6.1f TFLOP/s direct-equivalent; LDS %3zu KB; sclk %5.0f MHz %5.0f W (n=%d)\n", name, nch * 16, BIG ? 256 : 128,
          stage == 0 ? "staging off" : stage == 1 ? "staging on " : stage == 2 ? "stage: loads+split only" : stage == 3 ? "stage: no global loads" : "stage: LDS-DMA 2 steps ahead", us, tf, smem / 1024, n ? mhz / n : -1.0, n ? watts / n : -1.0, n);
   fflush(stdout);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -453,7 +456,17 @@ int main() {
   hipLaunchKernelGGL(fill_act, dim3(4096), dim3(256), 0, 0, act, act_floats);
   (void)hipDeviceSynchronize();
   const bool quick = getenv("TILE_SHAPES_STAGING") != nullptr;   // the staging ablations of the DIRECT skeleton only
+  const bool big = getenv("TILE_SHAPES_BN256") != nullptr;       // the 256-channel tile against the main tile on the Cout = 256 layers
   for (int rep = 0; rep < 2; ++rep) {
+    if (big) {
+      for (int nch : {16, 32}) {   // 256 -> 256 and 512 -> 256
+        run<false, 4, 1>("DIRECT main tile: 8 waves, 2 WG/CU, 128 channels", nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 1, true>("DIRECT 256-channel tile: 16 waves, 1 WG/CU", nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 0>("DIRECT main tile: 8 waves, 2 WG/CU, 128 channels", nch, w, wbytes, act, act_floats, scsh, out);
+        run<false, 4, 0, true>("DIRECT 256-channel tile: 16 waves, 1 WG/CU", nch, w, wbytes, act, act_floats, scsh, out);
+      }
+      continue;
+    }
     for (int nch : {8, 16}) {
       const char* D = "DIRECT main tile: 8 waves, 2 WG/CU";
       const char* W = "WINO F(2,3): 16 waves, 1 WG/CU, single weight slot";

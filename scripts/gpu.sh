@@ -125,7 +125,7 @@ PY
     done
     wait $PID
   done
-  cat $OUT/idle.txt $OUT/samples.txt; tail -2 $OUT/run_tile7.txt $OUT/run_tile6.txt ;;
+  cat $OUT/idle.txt $OUT/samples.txt; for f in $OUT/run_tile7.txt $OUT/run_tile6.txt; do tail -n 2 $f; done ;;
 ab)
   export ASYRP_LIBRARY=bench      # the product library reads no ASYRP_* switch
   i=0
