@@ -64,7 +64,7 @@ def save_pairs(path, pairs):
 
 def load_pairs(path):
     """torch.load(pairs_path, map_location='cpu') as the reference does (diffusion_latent.py:977)."""
-    pairs = torch.load(path, map_location=torch.device("cpu"), weights_only=False)
+    pairs = torch.load(path, map_location=torch.device("cpu"), weights_only=True)   # lists of tensors only: no pickled code
     for triple in pairs:
         if len(triple) != 3 or any(t.dim() != 4 or t.shape[0] != 1 for t in triple):
             raise ValueError(f"{path}: not a list of [x0, x_rec, x_lat] triples of [1,C,H,W] tensors")
@@ -102,7 +102,7 @@ def load_delta_checkpoints(model, paths):
     always key "0").  The model must already hold len(paths) DeltaBlocks (`setattr_layers`)."""
     m = model.module if isinstance(model, torch.nn.DataParallel) else model
     for i, p in enumerate(paths):
-        sd = torch.load(p, map_location="cpu", weights_only=False)["0"]
+        sd = torch.load(p, map_location="cpu", weights_only=True)["0"]     # a dict of tensors: no pickled code is executed
         res = getattr(m, f"layer_{i}").load_state_dict(sd)
         if res.missing_keys or res.unexpected_keys:
             raise KeyError(f"{p}: DeltaBlock keys do not match layer_{i}: {res}")
@@ -139,11 +139,34 @@ def delta_interpolation_coeffs(min_delta, max_delta, num_delta, hs_coeff=(1.0, 1
 
 
 @torch.no_grad()
-def edit_sweep(model, x_T, betas, hs_coeffs, **kw):
-    """Generation (loop B) once per hs_coeff tuple from the same latents, as save_image's outer loop does (:499-534).
-    Returns [len(hs_coeffs)] tensors [B,3,R,R].  (The strengths share x_T but not the trajectory: they are independent
-    batch entries, so this is `len(hs_coeffs)` engine calls on the already-resident weights.)"""
-    return [run_edit(model, x_T, betas, invert=False, hs_coeff=tuple(hc), **kw) for hc in hs_coeffs]
+def edit_sweep(model, x_T, betas, hs_coeffs, batched=True, **kw):
+    """Generation (loop B) for every hs_coeff tuple from the same latents, as save_image's outer loop does (:499-534).
+    Returns [len(hs_coeffs)] tensors [B,3,R,R].
+    batched (round 5): the tuples are independent of one another, so they run as BATCH ENTRIES -- x_T repeated per tuple, one
+    coefficient tuple per image (asyrp_run_edit with a per-image table), in chunks of the model's max_batch (<= 128 images) -- instead
+    of one engine pass per tuple as the reference loops; every image's bits equal those of the per-tuple pass (tested).  With B
+    images and K tuples this is ceil(B K / max_batch) passes instead of K (a 9-point strength sweep of one image: 1 pass, not 9)."""
+    hs_coeffs = [tuple(hc) for hc in hs_coeffs]
+    B, K = x_T.shape[0], len(hs_coeffs)
+    index = kw.get("index", 0)
+    cap = min(int(getattr(model, "max_batch", B)), 128)
+    if not batched or K <= 1 or index is None or index < 0 or cap < 2 * B or len({len(hc) for hc in hs_coeffs}) != 1 \
+            or len(hs_coeffs[0]) != index + 2:
+        return [run_edit(model, x_T, betas, invert=False, hs_coeff=hc, **kw) for hc in hs_coeffs]
+    if kw.get("noise") is not None:          # the eta = 1 tail draws / takes noise per batch entry: keep the reference's per-tuple passes
+        return [run_edit(model, x_T, betas, invert=False, hs_coeff=hc, **kw) for hc in hs_coeffs]
+    per_call = cap // B                        # tuples per engine call
+    out = []
+    for k0 in range(0, K, per_call):
+        chunk = hs_coeffs[k0:k0 + per_call]
+        xs = x_T.repeat(len(chunk), 1, 1, 1)                                   # [tuple][image] order
+        table = [hc for hc in chunk for _ in range(B)]
+        if len(chunk) == 1:
+            res = run_edit(model, x_T, betas, invert=False, hs_coeff=chunk[0], **kw)
+        else:
+            res = run_edit(model, xs, betas, invert=False, hs_coeff=table, **kw)
+        out.extend(res[i * B:(i + 1) * B] for i in range(len(chunk)))
+    return out
 
 
 # ---- global (mean) delta-h ----------------------------------------------------------------------------------------------

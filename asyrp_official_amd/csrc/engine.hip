@@ -591,6 +591,7 @@ struct Ctx {
   int B;
   float* tproj = nullptr;   // [B][tproj_total]
   const float* dh_in = nullptr;   // injected delta-h tensor (NHWC) -> slerp mix instead of the DeltaBlocks
+  int coeff_per_image = 0;        // hs_coeff is [B][index + 2]: one tuple per image (batched strength sweeps, asyrp_run_edit)
   int use_mask = 0;
   Tape* tape = nullptr;           // non-null while the training forward runs the DeltaBlock and decoder #2
   // dual-decoder steps (DDPM family): the skip-connection half of every decoder ResnetBlock's conv1 is the same in both
@@ -1494,7 +1495,8 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
     }
     Act h2;
     TRY(new_act(c, h.C, h.H, h.W, &h2));
-    HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
+    if (c.coeff_per_image) HIPCHK(launch_mix_per_image(h.p, dptr, coeff, index + 1, h2.p, c.B, h.per_image(), c.s));
+    else HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
     for (int i = 0; i < index; ++i) drop(c, deltas[i]);
     *last_delta = deltas[index];
     if (tape) tape->c1 = coeff[1];
@@ -1613,7 +1615,8 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
     }
     Act h2;
     TRY(new_act(c, h.C, h.H, h.W, &h2));
-    HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
+    if (c.coeff_per_image) HIPCHK(launch_mix_per_image(h.p, dptr, coeff, index + 1, h2.p, c.B, h.per_image(), c.s));
+    else HIPCHK(launch_mix(h.p, dptr, coeff, index + 1, h2.p, (long long)c.B * h.per_image(), c.s));
     for (int i = 0; i < index; ++i) drop(c, deltas[i]);
     *last_delta = deltas[index];
     if (tape) tape->c1 = coeff[1];
@@ -2244,12 +2247,20 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
   TRY(check_ready(e, B));
   if (!x0 || !x_edit || n_gen < 1 || !seq_gen || (n_inv > 0 && !seq_inv)) return fail(ASYRP_EINVAL, "bad argument");
   if (index >= e->cfg.n_delta) return fail(ASYRP_EINVAL, "index >= number of DeltaBlocks (setattr_layers)");
-  if (index >= 0 && (!hs_coeff_host || n_coeff < index + 2)) return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  // n_coeff < 0 (round 5, ABI v8): -n_coeff == B * (index + 2) entries, ONE TUPLE PER IMAGE (an editing-strength sweep as batch entries)
+  const bool per_image = n_coeff < 0;
+  if (per_image) {
+    if (index < 0 || !hs_coeff_host || -n_coeff != B * (index + 2)) return fail(ASYRP_EINVAL, "per-image hs_coeff: n_coeff must be -(B * (index + 2))");
+    if (B > MIX_MAX_IMAGES) return fail(ASYRP_EINVAL, "per-image hs_coeff: at most 128 images per call");
+  } else if (index >= 0 && (!hs_coeff_host || n_coeff < index + 2)) {
+    return fail(ASYRP_EINVAL, "hs_coeff needs index+2 entries");
+  }
   const asyrp_config& cf = e->cfg;
   if ((learn_sigma ? cf.out_channels / 2 : cf.out_channels) != 3 || cf.in_channels != 3)
     return fail(ASYRP_EINVAL, "edit loop expects 3 image channels");
   HIPCHK(hipSetDevice(e->device));
   Ctx c{e, (hipStream_t)stream, B};
+  c.coeff_per_image = per_image ? 1 : 0;
   PoolGuard guard{e};
   TRY(bind_stream(e, c.s));
   const int HW = cf.resolution * cf.resolution;

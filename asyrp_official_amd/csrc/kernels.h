@@ -220,6 +220,10 @@ hipError_t launch_linear_rows(const float* x, int ldx, const float* W, const flo
 // h2 = c0*h + sum_i c_{i+1} * d_i      (n_d <= 4), elementwise over `n` floats
 hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2,
                       long long n, hipStream_t s);
+// one coefficient tuple per image: coeff_host = [B][n_d + 1] (B <= MIX_MAX_IMAGES: the tuples travel as kernel arguments)
+constexpr int MIX_MAX_IMAGES = 128;
+hipError_t launch_mix_per_image(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2, int B,
+                                long long per_image, hipStream_t s);
 // h2 = slerp mix of h with an injected delta-h tensor (NHWC, one workgroup per sample); tt = 1 - hs_coeff[0]
 hipError_t launch_slerp_mix(const float* h, const float* dh, float tt, int use_mask, int B, int H, int W, int C, float* h2,
                             hipStream_t s);

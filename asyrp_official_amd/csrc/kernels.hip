@@ -756,6 +756,34 @@ hipError_t launch_mix(const float* h, const float* const* d, const float* coeff_
   return hipGetLastError();
 }
 
+// the same with ONE coefficient tuple PER IMAGE (round 5: batched editing-strength sweeps, cache.edit_sweep -- the reference runs one
+// generation pass per tuple, diffusion_latent.py:499-534/726-755; here the tuples are batch entries).  Same arithmetic and order per
+// element as mix_kernel, so an image's bits equal those of a whole-batch pass with its tuple.  blockIdx.y = image.
+struct MixImgArgs { const float* h; const float* d[4]; float c[MIX_MAX_IMAGES][5]; int n_d; float* out; long long per; };
+
+__global__ void mix_per_image_kernel(const MixImgArgs a) {
+  const int b = blockIdx.y;
+  const long long base = (long long)b * a.per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.per; i += (long long)gridDim.x * blockDim.x) {
+    float v = __fmul_rn(a.h[base + i], a.c[b][0]);
+    for (int k = 0; k < a.n_d; ++k) v = __fadd_rn(v, __fmul_rn(a.d[k][base + i], a.c[b][k + 1]));
+    a.out[base + i] = v;
+  }
+}
+
+hipError_t launch_mix_per_image(const float* h, const float* const* d, const float* coeff_host, int n_d, float* h2, int B,
+                                long long per_image, hipStream_t s) {
+  if (n_d < 0 || n_d > 4 || B < 1 || B > MIX_MAX_IMAGES) return hipErrorInvalidValue;
+  MixImgArgs a;
+  a.h = h; a.n_d = n_d; a.out = h2; a.per = per_image;
+  for (int k = 0; k < 4; ++k) a.d[k] = (k < n_d) ? d[k] : nullptr;
+  for (int b = 0; b < MIX_MAX_IMAGES; ++b)
+    for (int k = 0; k < 5; ++k) a.c[b][k] = (b < B && k <= n_d) ? coeff_host[(size_t)b * (n_d + 1) + k] : 0.f;
+  const int bx = (int)((per_image + 255) / 256 > 64 ? 64 : (per_image + 255) / 256);
+  hipLaunchKernelGGL(mix_per_image_kernel, dim3(bx, B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // =====================================================================================================
 // Injected delta-h: h2 = slerp(tt, h, |h| * dh / |dh|)  (models/ddpm/diffusion.py:6-40,531-539) or, with use_mask,
 // h2 = slerp(tt, h*m, dh*m) + (1-m)*h with m = 1 on rows 4..H-2, columns 3..4 (:519-529).  One workgroup per sample;

@@ -198,7 +198,14 @@ class Engine:
         n_noise = 0 if noise is None else int(noise.shape[0])
         x_T = torch.empty_like(x0) if want_latent else None
         x_edit = torch.empty_like(x0)
-        coeff, ncoeff = self._coeff(hs_coeff, idx)
+        if idx >= 0 and len(hs_coeff) > 0 and isinstance(hs_coeff[0], (tuple, list)):
+            # one tuple per image (a strength sweep as batch entries): [B][index + 2], signalled by a negative count (include/asyrp.h)
+            if len(hs_coeff) != B or any(len(hc) != idx + 2 for hc in hs_coeff):
+                raise ValueError(f"per-image hs_coeff must be {B} tuples of {idx + 2} coefficients")
+            flat = [float(v) for hc in hs_coeff for v in hc]
+            coeff, ncoeff = (C.c_float * len(flat))(*flat), -len(flat)
+        else:
+            coeff, ncoeff = self._coeff(hs_coeff, idx)
         with torch.cuda.device(self.device_index):
             _lib.check(self.lib.asyrp_run_edit(self.h, _ptr(x0), B, si, len(seq_inv), sg, len(seq_gen), int(t_edit),
                                                int(t_addnoise), idx, coeff, ncoeff, int(bool(learn_sigma)),

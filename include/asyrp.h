@@ -167,7 +167,11 @@ int asyrp_ddim_step(asyrp_engine* e, const float* xt, int t, int t_next, int B, 
  *   n_inv == 0 skips inversion and starts generation from x0 interpreted as x_T.
  *   The edit is applied for steps with t >= t_edit; eta = 1 for steps with t < t_addnoise, consuming
  *   noise[k] ([n_noise,B,3,R,R], nullable when no such step) in step order.
- *   x_T (nullable) receives the inverted latent. */
+ *   x_T (nullable) receives the inverted latent.
+ *   hs_coeff_host / n_coeff: index + 2 coefficients for the whole batch (as asyrp_ddim_step), or -- n_coeff < 0, -n_coeff ==
+ *   B * (index + 2) -- ONE TUPLE PER IMAGE, [B][index + 2]: the reference's editing-strength sweep (one generation pass per tuple,
+ *   diffusion_latent.py:499-534, 726-755) as batch entries of one call.  Per image the arithmetic is that of a whole-batch call with
+ *   its tuple (bit-identical; at most 128 images per call in this form). */
 int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_inv_host, int n_inv,
                    const int32_t* seq_gen_host, int n_gen, int t_edit, int t_addnoise, int index,
                    const float* hs_coeff_host, int n_coeff, int learn_sigma, const float* noise, int n_noise,

@@ -245,3 +245,38 @@ def test_1x1_kernel_pair_form_statistics():
     got_gn = y.cpu() * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
     want_gn = F.group_norm(want_y.double(), 32, gam.double(), bet.double(), eps=1e-6).float()
     assert_close(got_gn, want_gn, what="fused GN, pair form", rtol=1e-3, atol=1e-4)
+
+
+def test_strength_sweep_as_batch_entries_equals_per_tuple_passes():
+    """cache.edit_sweep (round 5): the coefficient tuples of an editing-strength sweep (diffusion_latent.py:726-755) run as batch entries
+    with ONE TUPLE PER IMAGE (asyrp_run_edit's per-image table) instead of one generation pass per tuple; every image of every tuple
+    must equal the per-tuple pass bit for bit -- single attribute (2 coefficients) and two attributes (3), chunking over max_batch."""
+    from asyrp_official_amd import cache
+    from oracle.weights import SMALL
+    for n_delta, index in ((1, 0), (2, 1)):
+        sd = synthetic(SMALL, n_delta, seed=21)
+        m = hip_model(SMALL, sd, n_delta, max_batch=6)
+        b = osamp.beta_schedule()
+        x_T = hash_normal(f"sweep.xT.{n_delta}", (2, 3, 32, 32), seed=5).cuda()
+        base = cache.make_hs_coeff(40, 6, n_attr=n_delta)
+        tuples = cache.delta_interpolation_coeffs(-1.0, 2.0, 4, hs_coeff=base) if n_delta == 1 else \
+            cache.delta_interpolation_coeffs(0.0, 1.5, 2, hs_coeff=base, multiple_attr=True)
+        kw = dict(n_gen=6, t_edit=400, index=index)
+        one_by_one = cache.edit_sweep(m, x_T, b, tuples, batched=False, **kw)
+        batched = cache.edit_sweep(m, x_T, b, tuples, batched=True, **kw)       # 4 tuples x 2 images over max_batch 6: two calls
+        assert len(batched) == len(tuples) == 4
+        for k, (a_, b_) in enumerate(zip(batched, one_by_one)):
+            assert a_.shape == x_T.shape and torch.equal(a_, b_), f"tuple {k}: batched sweep differs from the per-tuple pass"
+        assert not torch.equal(batched[0], batched[-1])                           # the strengths really differ
+
+
+def test_per_image_hs_coeff_is_validated():
+    from asyrp_official_amd import run_edit
+    from oracle.weights import SMALL
+    m = hip_model(SMALL, synthetic(SMALL, 1, seed=21), 1, max_batch=4)
+    b = osamp.beta_schedule()
+    x_T = hash_normal("sweep.bad", (2, 3, 32, 32), seed=5).cuda()
+    with pytest.raises(ValueError):
+        run_edit(m, x_T, b, invert=False, n_gen=4, hs_coeff=[(1.0, 1.0)] * 3)            # 3 tuples for 2 images
+    with pytest.raises(ValueError):
+        run_edit(m, x_T, b, invert=False, n_gen=4, hs_coeff=[(1.0, 1.0, 1.0)] * 2)       # wrong tuple length for index 0
