@@ -94,7 +94,9 @@ typedef struct asyrp_engine asyrp_engine;
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility push(default)
 #endif
-/* Version of this ABI (bumped on any signature change); asyrp_abi_version() returns the library's. */
+/* Version of this ABI (bumped on any signature or semantic change); asyrp_abi_version() returns the library's.
+ *   v8 (round 5): asyrp_config.nominal_batch (was reserved[0]) is validated (0, 1, 2, 32), the reserved words must be zero;
+ *                 asyrp_run_edit accepts one hs_coeff tuple per image (n_coeff < 0).  The product library reads no environment variable. */
 #define ASYRP_ABI_VERSION 8
 int asyrp_abi_version(void);
 

@@ -1,3 +1,9 @@
+#!/bin/bash
+# Same-box, interleaved whole-edit A/B of the round-4 tree against the working tree (profiles/r05j_ab_whole_edit_r04_vs_r05_same_box.txt).
+# The old tree is materialised next to the repo before the visit (it is git-ignored and removed afterwards):
+#   mkdir -p gpurun_ab/r04 && git archive 8e52766 -- asyrp_official_amd bench.py oracle include __graft_entry__.py | tar -x -C gpurun_ab/r04
+#   (cd gpurun_ab/r04 && mkdir -p profiles && python -m asyrp_official_amd.build)
+#   gpurun --timeout 900 -- 'bash scripts/ab_r04_vs_r05.sh'
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r05j; mkdir -p $OUT
 one() {  # one <dir> <label> <i>
