@@ -405,3 +405,40 @@ def test_product_library_reads_no_environment_switch():
     und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in und
 
+
+def test_edit_sweep_batches_the_tuples_and_keeps_their_order(monkeypatch):
+    """cache.edit_sweep's host logic (round 5) with a stand-in for the engine call: K coefficient tuples x B images run as batch
+    entries in [tuple][image] order, chunked by max_batch (<= 128), with one tuple per image; the result list is per tuple, as the
+    reference's per-tuple loop returns it (diffusion_latent.py:726-755, 499-534).  Fallbacks: batched=False, a single tuple, a model
+    whose max_batch cannot hold two tuples, supplied noise."""
+    from asyrp_official_amd import cache
+
+    calls = []
+
+    def fake_run_edit(model, x, betas, *, invert, hs_coeff, **kw):
+        calls.append((int(x.shape[0]), hs_coeff))
+        per = hs_coeff if isinstance(hs_coeff[0], (tuple, list)) else [hs_coeff] * x.shape[0]
+        assert len(per) == x.shape[0]
+        return torch.stack([x[i] * float(per[i][1]) + float(per[i][0]) for i in range(x.shape[0])])
+
+    monkeypatch.setattr(cache, "run_edit", fake_run_edit)
+
+    class M:
+        max_batch = 6
+
+    x_T = torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4)
+    tuples = cache.delta_interpolation_coeffs(-1.0, 2.0, 4, hs_coeff=(1.0, 0.5))
+    want = [x_T * hc[1] + hc[0] for hc in tuples]
+    got = cache.edit_sweep(M(), x_T, None, tuples, n_gen=4)
+    assert [c[0] for c in calls] == [6, 2]                     # 3 tuples x 2 images in the first call, the last tuple alone
+    assert isinstance(calls[0][1][0], tuple) and len(calls[0][1]) == 6 and calls[0][1][0] == calls[0][1][1] != calls[0][1][2]
+    assert len(got) == 4 and all(torch.equal(g, w) for g, w in zip(got, want))
+    for kwargs, n_calls in ((dict(batched=False), 4), (dict(noise=torch.zeros(1)), 4)):
+        calls.clear()
+        got = cache.edit_sweep(M(), x_T, None, tuples, n_gen=4, **kwargs)
+        assert len(calls) == n_calls and all(torch.equal(g, w) for g, w in zip(got, want))
+    M.max_batch = 3                                             # cannot hold two tuples of two images: one pass per tuple
+    calls.clear()
+    got = cache.edit_sweep(M(), x_T, None, tuples, n_gen=4)
+    assert len(calls) == 4 and all(torch.equal(g, w) for g, w in zip(got, want))
+
