@@ -13,10 +13,11 @@ from .ddpm import DDPM  # noqa: F401
 from .improved_ddpm import UNetModel, create_model, guided_Diffusion, i_DDPM  # noqa: F401
 from .diffusion_utils import denoising_step, extract, get_beta_schedule  # noqa: F401
 from .engine import AsyrpDeviceError, Engine  # noqa: F401
+from .data_parallel import DataParallel  # noqa: F401  (torch.nn.DataParallel without the per-forward parameter broadcast)
 from .sampler import gather_shards, run_edit, run_edit_sharded, shard_bounds, timestep_seq  # noqa: F401
 from . import cache  # noqa: F401  (latent-cache / Δh-checkpoint formats, hs_coeff schedules)
 from . import training  # noqa: F401  (DeltaBlock training step: autograd node over asyrp_train_forward / _backward)
 from .gaussian_diffusion import GaussianDiffusion  # noqa: F401  (vendored p_sample / ddim_sample / ddim_reverse_sample signatures)
 
 __all__ = ["DDPM", "UNetModel", "create_model", "i_DDPM", "guided_Diffusion", "denoising_step", "extract", "get_beta_schedule", "run_edit", "run_edit_sharded",
-           "timestep_seq", "shard_bounds", "gather_shards", "Engine", "AsyrpDeviceError", "GaussianDiffusion", "training", "cache"]
+           "timestep_seq", "shard_bounds", "gather_shards", "Engine", "AsyrpDeviceError", "GaussianDiffusion", "training", "cache", "DataParallel"]

@@ -1,5 +1,6 @@
 """Shared plumbing of the UNet mirrors: parameter holders with the reference's state_dict names + lazy HIP engine."""
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -37,6 +38,14 @@ def _default_init_(sd_items):
             p.uniform_(-bound, bound)
 
 
+class _EngineSlot:
+    """The engine of one device: created and re-synchronised under `lock`."""
+    __slots__ = ("engine", "sig", "uploaded", "lock")
+
+    def __init__(self):
+        self.engine, self.sig, self.uploaded, self.lock = None, None, {}, threading.RLock()
+
+
 class HipUNet(nn.Module):
     """Base of `DDPM` and `UNetModel`: owns reference-named parameters, creates/synchronises the HIP engine on demand.
     Subclasses provide `_make_cfg(n_delta)`, `_temb_freqs()` and `resolution`."""
@@ -52,12 +61,22 @@ class HipUNet(nn.Module):
         # not fp32-equivalent, reported separately with its own error; include/asyrp.h enum asyrp_conv_math)
         self.conv_math = conv_math
         self._n_delta = 0
-        self._engine = None
-        self._engine_sig = None
-        self._uploaded = {}
+        self._slots = {}                        # {device index: _EngineSlot}; shared with DataParallel replicas
+        self._slots_lock = threading.RLock()
         for key, shape in param_specs(self._make_cfg(0)):
             _attach(self, key, shape)
         _default_init_(list(self.named_parameters()))
+
+    def __getstate__(self):
+        # copy.deepcopy / pickling: engines and locks belong to this process and this object; the copy builds its own on demand
+        st = self.__dict__.copy()
+        st["_slots"], st["_slots_lock"] = {}, None
+        st.pop("_dp_source", None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._slots, self._slots_lock = {}, threading.RLock()
 
     # ---- reference surface ----------------------------------------------------------------------
     def setattr_layers(self, nums):
@@ -89,57 +108,102 @@ class HipUNet(nn.Module):
                                 ignore_timestep=ignore_timestep, delta_h=delta_h, use_mask=use_mask)
 
     # ---- engine plumbing ------------------------------------------------------------------------
+    # One engine per DEVICE, kept in `_slots` on the module the user built (the "source").  torch.nn.DataParallel replicas are
+    # shallow copies whose `__dict__["_dp_source"]` names the source: every replica drives the source's engine of ITS device and
+    # the engines take their weights from the source's parameters (by tensor version), never from the per-forward broadcast
+    # copies DataParallel hands the replicas.
+    def _src(self):
+        return self.__dict__.get("_dp_source", self)
+
+    @property
+    def _engine(self):
+        """The engine of the device the parameters live on (None before the first forward): single-device view of `_slots`."""
+        src = self._src()
+        p = next(src.parameters(), None)
+        if p is None or p.device.type != "cuda":
+            return None
+        slot = src._slots.get(p.device.index if p.device.index is not None else torch.cuda.current_device())
+        return slot.engine if slot is not None else None
+
     def _drop_engine(self):
-        if self._engine is not None:
-            self._engine.close()
-        self._engine, self._engine_sig, self._uploaded = None, None, {}
+        src = self._src()
+        with src._slots_lock:
+            slots, src._slots = list(src._slots.values()), {}
+        for slot in slots:
+            with slot.lock:
+                if slot.engine is not None:
+                    slot.engine.close()
+                slot.engine, slot.sig, slot.uploaded = None, None, {}
+
+    def _apply(self, fn, *a, **k):
+        # model.to(device) / .cuda(): engines of the devices left behind would keep their weights and workspace alive
+        before = {p.device for p in self.parameters()}
+        out = super()._apply(fn, *a, **k)
+        if {p.device for p in self.parameters()} != before and "_slots" in self.__dict__:
+            self._drop_engine()
+        return out
 
     def _replicate_for_data_parallel(self):
-        """torch.nn.DataParallel over MORE than one device (diffusion_latent.py:591 on a multi-GPU host) replicates the module per
-        device with shallow copies: every replica would drive ONE engine handle, bound to one GPU, from its own thread.  Fail loudly;
-        the supported multi-GPU form is one process per GPU (sampler.run_edit_sharded).  With a single device
-        DataParallel calls the module directly and never gets here."""
-        raise AsyrpDeviceError(f"{type(self).__name__} cannot be replicated by torch.nn.DataParallel across several GPUs: the HIP engine "
-                               "is bound to one device. Launch one process per GPU (torch.distributed.run) and use "
-                               "asyrp_official_amd.run_edit_sharded instead.")
+        """torch.nn.DataParallel (the reference's only multi-GPU form: diffusion_latent.py:179,195,591,1201) replicates the
+        module per device on EVERY forward and runs the replicas in threads.  A replica of the mirror is a light proxy: it shares
+        the source's per-device engine table, so replica j drives the engine bound to device j (created on first use, weights
+        uploaded once and re-synchronised when the SOURCE's parameters change — `model.module.layer_0.load_state_dict(...)`,
+        an optimiser step).  The parameter copies DataParallel broadcasts to the replica are never read."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_source"] = self._src()     # via __dict__: Module.__setattr__ would register it as a child
+        return replica
 
     def set_schedule(self, betas):
         """Hand the beta schedule (the `b` the reference passes to denoising_step) to the engine."""
-        self._betas = betas.detach().float().cpu().clone()
-        if self._engine is not None:
-            self._engine.set_schedule(alphas_cumprod_from_betas(self._betas))
+        src = self._src()
+        with src._slots_lock:
+            src._betas = betas.detach().float().cpu().clone()
+            slots = list(src._slots.values())
+        for slot in slots:
+            with slot.lock:
+                if slot.engine is not None:
+                    slot.engine.set_schedule(alphas_cumprod_from_betas(src._betas))
 
     def engine(self, device=None):
         """The live HIP engine for `device` (created, and parameters re-synchronised, on demand)."""
+        src = self._src()
         if device is None:
-            device = next(self.parameters()).device
+            device = next(src.parameters()).device
         device = torch.device(device)
         if device.type != "cuda":
             raise AsyrpDeviceError(f"{type(self).__name__} runs only on an MI355X (device type 'cuda' under ROCm); "
                                    "there is no CPU/PyTorch fallback")
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        sig = (idx, self._n_delta, self.max_batch, self.nominal_batch)
-        if self._engine is None or self._engine_sig != sig:
-            self._drop_engine()
-            self._engine = Engine(self._make_cfg(self._n_delta), self.max_batch, idx)
-            self._engine_sig = sig
-            self._engine.set_temb_freqs(self._temb_freqs())
-            if getattr(self, "_betas", None) is not None:
-                self._engine.set_schedule(alphas_cumprod_from_betas(self._betas))
-        dirty = False
-        for k, p in self.named_parameters():
-            stamp = (p.data_ptr(), p._version, tuple(p.shape))
-            if self._uploaded.get(k) != stamp:
-                self._engine.load_param(k, p)
-                self._uploaded[k] = stamp
-                dirty = True
-        if dirty:
-            self._engine.finalize()
-        return self._engine
+        with src._slots_lock:
+            slot = src._slots.get(idx)
+            if slot is None:
+                slot = src._slots[idx] = _EngineSlot()
+            sig = (idx, src._n_delta, src.max_batch, src.nominal_batch)
+        with slot.lock:
+            if slot.engine is None or slot.sig != sig:
+                if slot.engine is not None:
+                    slot.engine.close()
+                slot.engine, slot.uploaded = Engine(src._make_cfg(src._n_delta), sig[2], idx), {}
+                slot.sig = sig
+                slot.engine.set_temb_freqs(src._temb_freqs())
+                if getattr(src, "_betas", None) is not None:
+                    slot.engine.set_schedule(alphas_cumprod_from_betas(src._betas))
+            dirty = False
+            for k, p in src.named_parameters():
+                stamp = (p.data_ptr(), p._version, tuple(p.shape))
+                if slot.uploaded.get(k) != stamp:
+                    slot.engine.load_param(k, p)
+                    slot.uploaded[k] = stamp
+                    dirty = True
+            if dirty:
+                slot.engine.finalize()
+            return slot.engine
 
     def _ready_engine(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise AsyrpDeviceError("input must live on the GPU: the Asyrp HIP engine has no CPU fallback")
-        if x.shape[0] > self.max_batch:
-            self.max_batch = int(x.shape[0])
+        src = self._src()
+        with src._slots_lock:
+            if x.shape[0] > src.max_batch:
+                src.max_batch = int(x.shape[0])
         return self.engine(x.device)

@@ -3,7 +3,7 @@ denoising_step :24-104) on top of the HIP engine's fused DDIM step (asyrp_ddim_s
 import numpy as np
 import torch
 
-from . import training
+from . import data_parallel, training
 from ._base import HipUNet
 
 
@@ -53,7 +53,8 @@ def denoising_step(xt, t, t_next, *, models, logvars=None, b, sampling_type='ddi
     model = _unwrap(models)
     model.set_schedule(b) if getattr(model, "_betas", None) is None or not torch.equal(
         model._betas, b.detach().float().cpu()) else None
-    eng = model._ready_engine(xt)
+    if not (isinstance(xt, torch.Tensor) and xt.is_cuda):
+        model._ready_engine(xt)        # raises AsyrpDeviceError: no CPU path
     ti, tn = _uniform_int(t, "t"), _uniform_int(t_next, "t_next")
     apply_edit = index is not None and ti >= t_edit
     if training.wants_training(model, index, apply_edit):
@@ -64,9 +65,10 @@ def denoising_step(xt, t, t_next, *, models, logvars=None, b, sampling_type='ddi
                                    learn_sigma=learn_sigma)
     if eta != 0 and noise is None:
         noise = torch.randn_like(xt)
-    xt_next, x0_t, dh, mid = eng.ddim_step(xt, ti, tn, eta=float(eta), noise=noise if eta != 0 else None,
-                                           learn_sigma=learn_sigma, index=index, apply_edit=apply_edit,
-                                           hs_coeff=hs_coeff, ignore_timestep=ignore_timestep,
-                                           dt_lambda=float(dt_lambda), dt_end=int(dt_end), delta_h=delta_h,
-                                           use_mask=use_mask)
-    return xt_next, x0_t, dh, mid
+    step = dict(t=ti, t_next=tn, eta=float(eta), learn_sigma=learn_sigma, index=index, apply_edit=apply_edit, hs_coeff=hs_coeff,
+                ignore_timestep=ignore_timestep, dt_lambda=float(dt_lambda), dt_end=int(dt_end), use_mask=use_mask)
+    if xt.shape[0] > 1 and data_parallel.wrapper_devices(models):
+        # `models` is the reference's DataParallel wrapper over several GPUs (diffusion_latent.py:591): scatter the batch over its
+        # device_ids, one fused step per device engine and host thread, gather on output_device (data_parallel.sharded_step)
+        return data_parallel.sharded_step(models, model, xt, noise=noise if eta != 0 else None, delta_h=delta_h, **step)
+    return model._ready_engine(xt).ddim_step(xt, noise=noise if eta != 0 else None, delta_h=delta_h, **step)

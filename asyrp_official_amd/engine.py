@@ -1,6 +1,8 @@
 """Thin object wrapper over the C ABI: one Engine = one asyrp_engine on one GPU."""
 import ctypes as C
+import functools
 import math
+import threading
 
 import numpy as np
 import torch
@@ -67,9 +69,20 @@ class AsyrpDeviceError(RuntimeError):
     pass
 
 
+def _serialised(fn):
+    """One call at a time per engine: the engine recycles its workspace on one in-order stream (include/asyrp.h), and ctypes
+    releases the GIL, so two host threads sharing an engine (DataParallel replicas on ONE device) must take turns."""
+    @functools.wraps(fn)
+    def call(self, *a, **k):
+        with self.lock:
+            return fn(self, *a, **k)
+    return call
+
+
 class Engine:
     def __init__(self, cfg, max_batch, device_index):
         self.lib = _lib.load()
+        self.lock = threading.RLock()
         self.cfg, self.max_batch, self.device_index = cfg, int(max_batch), int(device_index)
         self.h = C.c_void_p()
         _lib.check(self.lib.asyrp_create(C.byref(self.h), C.byref(cfg), self.max_batch, self.device_index))
@@ -89,19 +102,23 @@ class Engine:
             pass
 
     # ---- parameters -------------------------------------------------------------------------------
+    @_serialised
     def load_param(self, key, tensor):
         a = np.ascontiguousarray(tensor.detach().float().cpu().numpy())
         shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
         _lib.check(self.lib.asyrp_load_param(self.h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
 
+    @_serialised
     def set_schedule(self, alphas_cumprod):
         a = np.ascontiguousarray(alphas_cumprod.detach().float().cpu().numpy())
         _lib.check(self.lib.asyrp_set_schedule(self.h, a.ctypes.data_as(C.c_void_p), a.size))
 
+    @_serialised
     def set_temb_freqs(self, freqs):
         a = np.ascontiguousarray(freqs.detach().float().cpu().numpy())
         _lib.check(self.lib.asyrp_set_temb_freqs(self.h, a.ctypes.data_as(C.c_void_p), a.size))
 
+    @_serialised
     def finalize(self):
         _lib.check(self.lib.asyrp_finalize_params(self.h))
 
@@ -142,6 +159,7 @@ class Engine:
             raise AsyrpDeviceError(f"{name} lives on {x.device}, the engine on cuda:{self.device_index}")
         return x
 
+    @_serialised
     def unet_forward(self, x, t, index=None, apply_edit=False, hs_coeff=(1.0, 1.0), ignore_timestep=False,
                      delta_h=None, use_mask=False):
         x = self._image(x, "x")
@@ -163,6 +181,7 @@ class Engine:
         # with an injected delta_h the reference hands the caller's own tensor back (diffusion.py:580)
         return et, et_mod, (delta_h if delta_h is not None else dh), mid
 
+    @_serialised
     def ddim_step(self, xt, t, t_next, *, eta=0.0, noise=None, learn_sigma=False, index=None, apply_edit=False,
                   hs_coeff=(1.0, 1.0), ignore_timestep=False, dt_lambda=1.0, dt_end=999, delta_h=None, use_mask=False):
         xt = self._image(xt, "xt")
@@ -184,6 +203,7 @@ class Engine:
                                                 _ptr(x0t), _ptr(dh), _ptr(mid), self._stream()))
         return xn, x0t, (delta_h if delta_h is not None else dh), mid
 
+    @_serialised
     def run_edit(self, x0, seq_inv, seq_gen, *, t_edit, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0),
                  learn_sigma=False, noise=None, want_latent=False):
         x0 = self._image(x0, "x0")
@@ -212,6 +232,7 @@ class Engine:
                                                _ptr(noise), n_noise, _ptr(x_T), _ptr(x_edit), self._stream()))
         return (x_edit, x_T) if want_latent else x_edit
 
+    @_serialised
     def run_inversion(self, x0, seq_inv, *, learn_sigma=False, tap_first=0, tap_count=0, want_x=True, want_x0t=True):
         """DDIM inversion with a per-step read-out (asyrp_run_inversion): returns (x_last, x_tap, x0t_tap), the taps shaped
         [tap_count, B, 3, R, R] (None when not requested / tap_count == 0)."""
@@ -229,6 +250,7 @@ class Engine:
         return x_last, x_tap, x0t_tap
 
     # ---- DeltaBlock training step (asyrp_train_forward / asyrp_train_backward) ----------------------
+    @_serialised
     def train_forward(self, xt, t, t_next, *, hs_coeff=(1.0, 1.0), ignore_timestep=False, learn_sigma=False):
         """-> (xt_next, x0_t, delta_h, middle_h, tape_id); `tape_id` names the recorded step for train_backward / train_discard."""
         xt = self._image(xt, "xt")
@@ -246,6 +268,7 @@ class Engine:
         self._tape_batch = {int(tid.value): B}
         return xn, x0t, dh, mid, int(tid.value)
 
+    @_serialised
     def train_backward(self, tape_id, d_et_mod, named_shapes):
         """d_et_mod [B,Cout,R,R] for the step `tape_id`; named_shapes: [(state_dict key, shape)] of DeltaBlock parameters ->
         list of gradients (zero-initialised device tensors the engine fills)."""
@@ -268,6 +291,7 @@ class Engine:
         if self.h:
             self.lib.asyrp_train_discard(self.h, int(tape_id))
 
+    @_serialised
     def get_temb(self, t):
         t = _dev_f32(t.float() if isinstance(t, torch.Tensor) else t, "t")
         out = torch.empty((t.shape[0], self.cfg.ch * 4), device=t.device, dtype=torch.float32)

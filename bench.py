@@ -237,6 +237,54 @@ def bench_config(a):
     return family, family != "ddpm", B, workload, baseline
 
 
+def other_config_sample(name, dev, betas, conv_math, reuse=None):
+    """ONE timed edit of another BASELINE configuration (outside the headline's timed region; a 1-edit sample, not a benchmark):
+    images/s, the dominant kernel's roofline fraction from the same HIP-event record, and the bitwise batch-invariance flag (the
+    last image edited alone == its row of the batch, full 39+40 steps).  `reuse` = (model, engine) when the configuration runs the
+    headline's own UNet (configs/church.yml has configs/celeba.yml's model block)."""
+    from asyrp_official_amd import i_DDPM, run_edit
+    cfg = argparse.Namespace(config=name, batch=0)
+    family, learn_sigma, B, workload, baseline_cfg = bench_config(cfg)
+    t_build = time.perf_counter()
+    if reuse is not None:
+        model, eng = reuse
+    else:
+        torch.manual_seed(1234)
+        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=B, conv_math=conv_math)
+        model.setattr_layers(1)
+        model = model.to(dev).eval()
+        eng = model.engine(dev)
+    model.set_schedule(betas)
+    x0 = (2 * torch.rand((B, 3, 256, 256), generator=torch.Generator().manual_seed(4321)) - 1).to(dev)
+    kw = dict(t_0=T_0, t_edit=T_EDIT, t_addnoise=0, index=0, hs_coeff=(1.0, 1.0), learn_sigma=learn_sigma)
+    run_edit(model, x0, betas, n_inv=3, n_gen=2, **kw)       # untimed: workspace allocation, every kernel of both decoder passes
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    eng.profile_read()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    out = run_edit(model, x0, betas, n_inv=N_INV, n_gen=N_GEN, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    prof = eng.profile_read()
+    alone = run_edit(model, x0[B - 1:].contiguous(), betas, n_inv=N_INV, n_gen=N_GEN, **kw)
+    res = {"workload": workload, "baseline_config": baseline_cfg, "batch_per_gpu": B, "sample": "1 edit, timed once (after an untimed 2+2-step pass that allocates the workspace)",
+           "images_per_s": B / dt, "ms_per_edit": 1e3 * dt, "finite": bool(torch.isfinite(out).all()),
+           "batch_invariance_bitwise": bool(torch.equal(alone[0], out[B - 1])), "setup_s": t_build}
+    if prof and prof["launches"]:
+        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+        peak = F16_MFMA_PEAK_TFLOPS / (1.0 if conv_math == "f16" else 3.0)
+        res["dominant_kernel"] = {"kernel": prof["kernel"], "tflops": ach, "frac_of_mfma_bound": ach / peak,
+                                  "share_of_edit": prof["ms"] * 1e-3 / dt, "launches": prof["launches"]}
+    if reuse is None:
+        model._drop_engine()
+        del model, eng
+    del x0, out, alone
+    torch.cuda.empty_cache()
+    return res
+
+
 def engine_device_index(local_rank, backend, ndev):
     """The device a rank builds its engine on: its LOCAL_RANK under RCCL (one process per GPU); ranks share devices only in the gloo
     dry run on a box with fewer GPUs than ranks."""
@@ -351,6 +399,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the one-edit samples of BASELINE configs 2, 3, 4 that the default 1-GPU celeba line carries in `other_configs`")
     ap.add_argument("--plumbing-dry-run", action="store_true",
                     help="NO engine, NO GPU: run only the N-rank skeleton of this file (self-launch, rendezvous, per-rank seeds, barrier + "
                          "max-over-ranks timing, shard -> all-gather, the JSON line) on CPU tensors with a stand-in per-image function; "
@@ -413,6 +463,28 @@ def main():
         prof = eng.profile_read()
     assert torch.isfinite(out).all(), "non-finite output"
     assert out.shape[0] == B * world
+
+    # ---- evidence that the N ranks did N different shards and that the one collective delivered them (outside the timed region) ----
+    gather_check = None
+    if world > 1:
+        import hashlib
+        sha = lambda t_: hashlib.sha256(t_.detach().cpu().contiguous().numpy().tobytes()).hexdigest()   # noqa: E731
+        mine = (rank, 1234 + rank, dev_index, os.getpid(), sha(out_local), [sha(out[r * B:(r + 1) * B]) for r in range(world)])
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        if rank == 0:
+            gather_check = {"world_size": world, "rank_seeds": [g_[1] for g_ in got], "engine_device_index_per_rank": [g_[2] for g_ in got],
+                            "distinct_processes": len({g_[3] for g_ in got}) == world,
+                            # every rank's own result is the slice every OTHER rank received for it
+                            "gathered_slices_equal_rank_results_sha256": all(g_[5][r] == got[r][4] for g_ in got for r in range(world)),
+                            "shards_differ": len({g_[4] for g_ in got}) == world}
+            if B * world <= 16:
+                # small runs only: rank 0 rebuilds every rank's input from its seed and edits the whole batch on ITS engine in one call
+                xs = torch.cat([2 * torch.rand((B, 3, 256, 256), generator=torch.Generator().manual_seed(sd_)) - 1
+                                for sd_ in gather_check["rank_seeds"]]).to(dev)
+                whole = run_edit(model, xs, betas, **edit_kw)
+                gather_check["gathered_equals_unsharded_bitwise"] = bool(torch.equal(whole, out))
+                del xs, whole
 
     # ---- parity at the benchmarked configuration (outside the timed region) ----------------------------------------
     # (1) batch invariance: images 0 and B-1 edited ALONE (B=1) must equal their rows of the batched result bit for bit
@@ -564,6 +636,24 @@ def main():
         if parity is not None:
             res["parity_check"] = parity
             if not parity["batch_invariance_bitwise"]:
+                rc = 1
+        if gather_check is not None:
+            res["gather_check"] = gather_check
+            if not (gather_check["gathered_slices_equal_rank_results_sha256"] and gather_check.get("gathered_equals_unsharded_bitwise", True)):
+                rc = 1
+        if world == 1 and a.config == "celeba" and not a.batch and not a.no_other_configs and a.conv_math != "f32":
+            # BASELINE configs 2, 3 (per GPU) and 4 (per GPU): never the headline, never inside its timed region; each a 1-edit sample
+            del out, out_local
+            oc = {"church": other_config_sample("church", dev, betas, a.conv_math, reuse=(model, eng))}
+            model._drop_engine()
+            torch.cuda.empty_cache()
+            for name in ("afhq", "imagenet"):
+                try:
+                    oc[name] = other_config_sample(name, dev, betas, a.conv_math)
+                except Exception as e:   # noqa: BLE001   a sample must not take the headline line down with it
+                    oc[name] = {"error": f"{type(e).__name__}: {e}"}
+            res["other_configs"] = oc
+            if any(v.get("batch_invariance_bitwise") is False for v in oc.values()):
                 rc = 1
         print(json.dumps(res), flush=True)
         if rc:

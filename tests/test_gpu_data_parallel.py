@@ -1,0 +1,191 @@
+"""The reference's multi-GPU call shape on the engine mirror: `model = torch.nn.DataParallel(model)` (diffusion_latent.py:179,195,591,
+1201), `model.module.layer_i` (:182,252,288,675), and B1 `models(xt, t, index=, t_edit=, hs_coeff=, ...)` through the wrapper
+(utils/diffusion_utils.py:46).
+
+On a 1-GPU box DataParallel's own broadcast refuses duplicate device ids, so the stock path is exercised one level below it — the
+same replicate -> threads -> gather shape with both replicas on device 0 — and everything above it (scatter, replicate, parallel_apply,
+gather of the 4-tuple with its None entries) through `asyrp_official_amd.DataParallel(device_ids=[0, 0])`, whose replicate() does not
+broadcast.  The real `torch.nn.DataParallel` over >= 2 GPUs runs where two are visible.  Every comparison is BITWISE against the
+unwrapped model: an image's result does not depend on its batch, so any scatter must reproduce it exactly."""
+import pytest
+import torch
+from torch.nn.parallel import gather, parallel_apply, replicate
+from torch.nn.parallel.scatter_gather import scatter_kwargs
+
+from oracle import sampler as osamp
+from oracle.weights import SMALL, hash_normal
+from util_models import hip_model, synthetic
+
+pytestmark = pytest.mark.gpu
+
+EDIT = dict(index=0, t_edit=500, hs_coeff=(1.0, 1.0))
+NAMES = ("et", "et_modified", "delta_h", "middle_h")
+
+
+@pytest.fixture(scope="module")
+def model():
+    sd = synthetic(SMALL, 1, seed=11)
+    return hip_model(SMALL, sd, 1, max_batch=8), sd
+
+
+def _x(B, seed=0):
+    return hash_normal("dp.x", (B, 3, 32, 32), seed=seed).cuda()
+
+
+def _same(got, want, what):
+    assert len(got) == len(want) == 4
+    for name, g, w in zip(NAMES, got, want):
+        if w is None:
+            assert g is None, f"{what}: {name} should be None"
+        else:
+            assert g is not None and g.shape == w.shape and torch.equal(g, w), f"{what}: {name} differs from the unwrapped model"
+
+
+def _two_thread_forward(m, x, t, **kw):
+    """DataParallel.forward one level below the wrapper: scatter -> _replicate_for_data_parallel per chunk -> parallel_apply (threads)
+    -> gather, with every chunk on device 0."""
+    inputs, kwargs = scatter_kwargs((x, t), kw, [0, 0])
+    # torch pads the positional chunks with () when non-tensor kwargs outnumber them (batch 1 on two devices): the stock wrapper then
+    # calls the second replica without x — its own defect, for the reference's DDPM too (data_parallel.DataParallel.scatter drops the
+    # padding; the reference's scripts pin one GPU).  Keep the chunks that exist.
+    n = sum(1 for i in inputs if len(i) > 0)
+    inputs, kwargs = inputs[:n], kwargs[:n]
+    reps = [m._replicate_for_data_parallel() for _ in inputs]
+    outs = parallel_apply(reps, inputs, kwargs, devices=[0, 0][: len(inputs)])
+    return gather(outs, 0)
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_two_replicas_in_two_threads_equal_the_unwrapped_model_bitwise(model, B):
+    m, sd = model
+    x = _x(B, seed=B)
+    for tval, tag in ((701.0, "t >= t_edit (dual decoder)"), (225.0, "t < t_edit")):
+        t = torch.full((B,), tval, device="cuda")
+        want = m(x, t, **EDIT)
+        _same(_two_thread_forward(m, x, t, **EDIT), want, f"B={B} {tag}")
+    # no index: plain eps, et_modified None (models/ddpm/diffusion.py:541-580)
+    t = torch.full((B,), 701.0, device="cuda")
+    _same(_two_thread_forward(m, x, t), m(x, t), f"B={B} index=None")
+    # the reference re-loads layer_i through the wrapper's .module between runs (diffusion_latent.py:674-676): replicas must see it
+    before = m(x, t, **EDIT)
+    new = {k: v * 1.5 + 0.01 for k, v in m.layer_0.state_dict().items()}
+    m.layer_0.load_state_dict(new)
+    try:
+        got = _two_thread_forward(m, x, t, **EDIT)
+        want = m(x, t, **EDIT)
+        _same(got, want, f"B={B} after layer_0 reload")
+        assert not torch.equal(want[1], before[1]), "the re-loaded DeltaBlock did not reach the engine"
+    finally:
+        m.layer_0.load_state_dict({k: sd["layer_0." + k] for k in new})
+    _same(_two_thread_forward(m, x, t, **EDIT), before, f"B={B} after restoring layer_0")
+
+
+def test_stock_replicate_on_one_device_is_what_a_batch_of_one_does_on_a_multi_gpu_node(model):
+    """On an 8-GPU node the reference's inversion (batch 1, diffusion_latent.py:1010,1038) makes DataParallel.forward call the STOCK
+    replicate(module, device_ids[:1]) — parameter broadcast included — and run that replica.  Round 5 raised here."""
+    m, _ = model
+    x, t = _x(1, seed=3), torch.full((1,), 701.0, device="cuda")
+    want = m(x, t, **EDIT)
+    (rep,) = replicate(m, [0])
+    assert rep._src() is m and rep is not m
+    _same(rep(x, t, **EDIT), want, "stock replicate([0])")
+    assert len(m._slots) == 1, "a replica created an engine of its own instead of using the source's"
+
+
+@pytest.mark.parametrize("B", [2, 5])
+def test_wrapper_forward_scatter_replicate_threads_gather(model, B):
+    """The whole DataParallel.forward — scatter, replicate, parallel_apply, gather — with asyrp_official_amd.DataParallel over
+    device_ids [0, 0] (its replicate() does not broadcast, so duplicate ids are legal on a 1-GPU box)."""
+    from asyrp_official_amd import DataParallel
+    m, _ = model
+    w = DataParallel(m, device_ids=[0, 0])
+    assert w.module is m and w.module.layer_0 is m.layer_0
+    x1, t1 = _x(1, seed=19), torch.full((1,), 701.0, device="cuda")
+    _same(w(x1, t1, **EDIT), m(x1, t1, **EDIT), "wrapper forward, batch of one on two device entries (scatter padding dropped)")
+    x = _x(B, seed=20 + B)
+    for tval in (701.0, 225.0):
+        t = torch.full((B,), tval, device="cuda")
+        _same(w(x, t, **EDIT), m(x, t, **EDIT), f"wrapper forward B={B} t={tval}")
+    # an injected delta_h tensor is scattered with the batch (models/ddpm/diffusion.py:518-539)
+    t = torch.full((B,), 701.0, device="cuda")
+    dh = hash_normal("dp.dh", (B, 64, 8, 8), seed=B).cuda()
+    got, want = w(x, t, delta_h=dh, **EDIT), m(x, t, delta_h=dh, **EDIT)
+    for name, g, v in zip(NAMES, got, want):
+        assert torch.equal(g, v), f"injected delta_h: {name}"
+
+
+def test_denoising_step_through_the_wrapper_shards_the_batch(model):
+    """B2 with `models=` the DataParallel wrapper (how diffusion_latent.py:308,507,1038 call it): the batch is scattered over the
+    wrapper's device_ids, one fused step per chunk and thread, gathered — bitwise the unwrapped step, incl. the eta = 1 tail with
+    supplied noise and the injected-delta_h branch (whose tensor is handed back as the caller's own object)."""
+    from asyrp_official_amd import DataParallel, denoising_step
+    m, _ = model
+    w = DataParallel(m, device_ids=[0, 0])
+    b = osamp.beta_schedule().cuda()
+    B = 5
+    x = _x(B, seed=31)
+    one = torch.ones(B, device="cuda")
+    kw = dict(logvars=None, b=b, sampling_type="ddim")
+    cases = [dict(t=one * 701, t_next=one * 675, eta=0.0, **EDIT),
+             dict(t=one * 225, t_next=one * 200, eta=0.0, **EDIT),
+             dict(t=one * 0, t_next=one * 25, eta=0.0),
+             dict(t=one * 25, t_next=one * 0, eta=1.0, noise=hash_normal("dp.noise", (B, 3, 32, 32)).cuda(), **EDIT),
+             dict(t=one * 0, t_next=one * -1, eta=0.0, **EDIT)]
+    for c in cases:
+        got = denoising_step(x, models=w, **c, **kw)
+        want = denoising_step(x, models=m, **c, **kw)
+        for name, g, v in zip(("xt_next", "x0_t", "delta_h", "middle_h"), got, want):
+            assert (g is None and v is None) or torch.equal(g, v), f"{name} t={float(c['t'][0])}"
+    dh = hash_normal("dp.dh2", (B, 64, 8, 8)).cuda()
+    got = denoising_step(x, models=w, t=one * 701, t_next=one * 675, eta=0.0, delta_h=dh, **EDIT, **kw)
+    want = denoising_step(x, models=m, t=one * 701, t_next=one * 675, eta=0.0, delta_h=dh, **EDIT, **kw)
+    assert got[2] is dh and all(torch.equal(g, v) for g, v in zip(got, want))
+
+
+def test_engine_calls_from_concurrent_threads_are_serialised_and_deterministic(model):
+    """Eight host threads hammer ONE device engine through replicas (what DataParallel does when device ids repeat): every call must
+    return the bits of the single-threaded call — the engine recycles its workspace on one in-order stream, so calls take turns."""
+    import threading
+    m, _ = model
+    xs = [_x(1 + (i % 3), seed=40 + i) for i in range(8)]
+    ts = [torch.full((x.shape[0],), 701.0 if i % 2 else 225.0, device="cuda") for i, x in enumerate(xs)]
+    want = [m(x, t, **EDIT) for x, t in zip(xs, ts)]
+    got, errs = [None] * 8, []
+
+    def work(i):
+        try:
+            rep = m._replicate_for_data_parallel()
+            for _ in range(3):
+                got[i] = rep(xs[i], ts[i], **EDIT)
+        except Exception as e:    # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for i in range(8):
+        _same(got[i], want[i], f"thread {i}")
+
+
+need2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
+
+
+@need2
+@pytest.mark.parametrize("wrapper", ["torch", "asyrp"])
+def test_real_data_parallel_over_two_gpus(model, wrapper):
+    """torch.nn.DataParallel(model) as the reference writes it, over two real devices: batch 1 (one replica) and batch 5 (two)."""
+    from asyrp_official_amd import DataParallel, denoising_step
+    m, _ = model
+    w = (torch.nn.DataParallel if wrapper == "torch" else DataParallel)(m, device_ids=[0, 1])
+    b = osamp.beta_schedule().cuda()
+    # batch 1 through the stock wrapper dies in torch's own scatter (see data_parallel.DataParallel); batch 2 is one image per device
+    for B in ((2, 5) if wrapper == "torch" else (1, 2, 5)):
+        x, t = _x(B, seed=50 + B), torch.full((B,), 701.0, device="cuda:0")
+        _same(w(x, t, **EDIT), m(x, t, **EDIT), f"{wrapper} DataParallel over [0, 1], B={B}")
+        one = torch.ones(B, device="cuda:0")
+        got = denoising_step(x, t=one * 701, t_next=one * 675, models=w, logvars=None, b=b, sampling_type="ddim", eta=0.0, **EDIT)
+        want = denoising_step(x, t=one * 701, t_next=one * 675, models=m, logvars=None, b=b, sampling_type="ddim", eta=0.0, **EDIT)
+        assert all(torch.equal(g, v) for g, v in zip(got, want))
+    assert set(m._slots) == {0, 1}

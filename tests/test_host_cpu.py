@@ -384,15 +384,52 @@ def test_batch_class_values_are_validated_before_they_reach_the_library():
     assert "asyrp_config.reserved must be zero" in src and "nominal_batch must be 0" in src
 
 
-def test_data_parallel_replication_fails_loudly():
-    """nn.DataParallel with N > 1 devices (the reference's only multi-GPU form, diffusion_latent.py:591) must not replicate the engine
-    mirror: replicas are shallow copies that would share one engine handle across threads and devices."""
-    from asyrp_official_amd import DDPM, AsyrpDeviceError, i_DDPM
+def test_data_parallel_replicas_are_light_proxies_of_the_source():
+    """torch.nn.DataParallel (the reference's only multi-GPU form, diffusion_latent.py:179,195,591,1201) replicates the module per
+    device on every forward.  A replica of the mirror must (i) exist — round 5 raised here, which killed the unmodified edit script on
+    a multi-GPU node at its first UNet call — (ii) share the SOURCE's per-device engine table and lock, (iii) name
+    the source, also when a replica is replicated again, (iv) not be registered as a child module, and the source must stay
+    deep-copyable / picklable (engines and locks are per process)."""
+    import copy
+    import pickle
+    from asyrp_official_amd import DDPM, DataParallel, i_DDPM
+    from asyrp_official_amd._base import HipUNet
     sys.path.insert(0, ROOT)
     import bench
     for m in (DDPM(bench.celeba_namespace(), max_batch=1), i_DDPM("AFHQ", max_batch=1)):
-        with pytest.raises(AsyrpDeviceError, match="one process per GPU"):
-            m._replicate_for_data_parallel()
+        m.setattr_layers(1)
+        n_children = len(list(m.children()))
+        r = m._replicate_for_data_parallel()
+        assert isinstance(r, HipUNet) and r is not m and r._src() is m and m._src() is m
+        assert r._slots is m._slots and r._slots_lock is m._slots_lock
+        assert r._replicate_for_data_parallel()._src() is m
+        assert len(list(m.children())) == n_children and "_dp_source" not in m._modules and "_dp_source" not in r._modules
+        assert m._engine is None                                   # nothing is created before the first forward (CPU parameters)
+        # the reference's post-wrap accesses (diffusion_latent.py:284,288,675) reach the source's parameters
+        w = DataParallel(m, device_ids=None) if torch.cuda.is_available() else None
+        sd = {k: torch.full_like(v, 0.25) for k, v in m.layer_0.state_dict().items()}
+        (w.module if w is not None else m).layer_0.load_state_dict(sd)
+        assert all(bool((p == 0.25).all()) for p in r._src().layer_0.parameters())
+        m2 = copy.deepcopy(m)
+        assert m2._slots == {} and m2._slots is not m._slots and m2._slots_lock is not m._slots_lock
+        assert all(torch.equal(a, b) for a, b in zip(m2.layer_0.parameters(), m.layer_0.parameters()))
+        m3 = pickle.loads(pickle.dumps(m))
+        assert m3._slots == {} and set(m3.state_dict()) == set(m.state_dict())
+
+
+def test_data_parallel_subclass_skips_the_parameter_broadcast():
+    """asyrp_official_amd.DataParallel.replicate: one light proxy per device for an engine-backed module (no broadcast: the stock
+    replicate() copies every parameter to every device on every forward), the stock path for anything else."""
+    from asyrp_official_amd import DDPM, DataParallel
+    from asyrp_official_amd.data_parallel import wrapper_devices
+    sys.path.insert(0, ROOT)
+    import bench
+    m = DDPM(bench.celeba_namespace(), max_batch=1)
+    w = DataParallel.__new__(DataParallel)              # the constructor needs visible GPUs; replicate() itself does not
+    reps = DataParallel.replicate(w, m, [0, 1, 2])
+    assert len(reps) == 3 and all(r._src() is m and r._slots is m._slots for r in reps) and len({id(r) for r in reps}) == 3
+    assert all(not r._parameters for r in reps)
+    assert wrapper_devices(m) is None
 
 
 def test_product_library_reads_no_environment_switch():
