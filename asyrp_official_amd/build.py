@@ -9,7 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = PRODUCT_LIB = os.path.join(HERE, "libasyrp_hip.so")
 BENCH_LIB = os.path.join(HERE, "libasyrp_hip_bench.so")
 SOURCES = ["kernels.hip", "conv_f16x3.hip", "conv_out.hip", "conv_in.hip", "gemm1x1.hip", "attention.hip", "backward.hip", "engine.hip"]
-DEPS = SOURCES + ["kernels.h", os.path.join("..", "..", "include", "asyrp.h")]
+BENCH_SOURCES = SOURCES + ["bench_hooks.hip"]   # the profiling library only (-DASYRP_BENCH_HOOKS): micro-benchmark / phase-stamp entry points
+DEPS = BENCH_SOURCES + ["kernels.h", os.path.join("..", "..", "include", "asyrp.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-comment",
          "-fvisibility=hidden"]   # exports = the extern "C" entry points of include/asyrp.h (visibility pragma there)
 
@@ -25,7 +26,8 @@ def needs_build(lib=PRODUCT_LIB):
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    deps = DEPS if lib == BENCH_LIB else [d for d in DEPS if d != "bench_hooks.hip"]
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
 
 
 def build_library(force=False, verbose=True, bench_hooks=False):
@@ -54,8 +56,9 @@ def build_library(force=False, verbose=True, bench_hooks=False):
         subprocess.run(cmd, check=True, cwd=CSRC)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    sources = BENCH_SOURCES if bench_hooks else SOURCES
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(compile_one, sources))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print("[asyrp build]", " ".join(cmd), flush=True)

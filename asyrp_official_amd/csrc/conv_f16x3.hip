@@ -1024,17 +1024,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       int sp = aoff[i];
       asm volatile("" : "+v"(sp));   // (laundered: the 64-bit row offsets of both sources are otherwise hoisted out of the K loop and
                                      //  held across the matrix passes, where every register counts)
-#ifdef K32_EXP_NO_STAGE_LOAD   // (timing experiment: the staging pass without its global loads)
-      v0 = make_float4(0.5f + chunk, 1.f, -1.f, 0.25f);
-      v1 = v0;
-      asm volatile("" : "+v"(v0.x), "+v"(v1.y));
-#else
       if (sp >= 0) {
         const float* src = base + (long long)sp * ld;
         v0 = *reinterpret_cast<const float4*>(src);
         v1 = *reinterpret_cast<const float4*>(src + 4);
       }
-#endif
       areg[i][0] = v0;
       areg[i][1] = v1;
     }
@@ -1063,7 +1057,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
       const float sh[8] = {sreg[2].x, sreg[2].y, sreg[2].z, sreg[2].w, sreg[3].x, sreg[3].y, sreg[3].z, sreg[3].w};
       float t[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
                     areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
-#ifndef K32_EXP_NO_STAGE_MATH   // (timing experiment: the staging pass without GroupNorm-apply / SiLU)
       if (aoff[i] >= 0) {
         if (ps) {
 #pragma unroll
@@ -1074,7 +1067,6 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
           for (int j = 0; j < 8; ++j) t[j] = silu_fast(t[j]);
         }
       }
-#endif
       int t_ = tid;
       asm volatile("" : "+v"(t_));   // (laundered, as above)
       const int pix = (t_ + i * NT) >> 1;
@@ -1232,9 +1224,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
   const int nsteps = nsteps3 + nsc;
   int c0 = cb, t0 = 0, staged = cb;   // (c0, t0): chunk and tap of the step's first slice
   for (int s = s_first; s < nsteps3; ++s) {
-#ifndef K32_EXP_NO_DMA   // (timing experiments on the PRODUCT instantiation: -DK32_EXP_NO_DMA / -DK32_EXP_NO_STAGE builds of the profiling library)
     if (s + 1 < nsteps && !(abl & 2)) issue_slot(s + 1, (s + 1) & 1);
-#endif
     int c1 = c0, t1 = t0 + 1;
     if (t1 == NTAPS) { t1 = 0; ++c1; }
     const int ky0 = (KW == 3) ? (t0 * 11) >> 5 : t0 >> 1, ky1 = (KW == 3) ? (t1 * 11) >> 5 : t1 >> 1;   // t / KW
@@ -1249,13 +1239,11 @@ __global__ void __launch_bounds__(T::NT, T::MINW) igemm_f16x3_k32_kernel(const G
     // the halo tile of the chunk the NEXT step's second slice belongs to must be in LDS before the barrier below; its
     // buffer held chunk need-2, last read at least one barrier ago
     const int need = (t0 == NTAPS - 1) ? c0 + 1 : c0;
-#ifndef K32_EXP_NO_STAGE
     if (need > staged && need < ce && !(abl & 8)) {
       gload_A(need);
       write_A(need, need & 1);
       staged = need;
     }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

@@ -19,6 +19,9 @@ inline const char* ab_env(const char* name) {
 #endif
 }
 
+// records the calling thread's error string (what asyrp_last_error returns) and hands `code` back; defined in engine.hip
+int set_last_error(int code, const char* msg);
+
 // One implicit-GEMM launch: out[z][m][n] = alpha * sum_k A[z][m][k] * B[(z)][k][n] (+bias +chan_add +resid)
 //   A = activations, NHWC, up to two channel-concatenated sources, optional per-(image,channel)
 //       affine (GroupNorm apply / FiLM) + SiLU prologue, optional nearest-x2 upsample, 3x3 halo via LDS.

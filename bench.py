@@ -427,10 +427,13 @@ def main():
 
     family, learn_sigma, B, workload, baseline_cfg = bench_config(a)
     torch.manual_seed(1234)                     # main.py:301 default seed
+    # small multi-rank runs re-edit the WHOLE gathered batch on rank 0 for gather_check: size the engine for it up front (growing
+    # max_batch later would re-create the engine under the handles taken below)
+    max_b = B * world if (world > 1 and B * world <= 16) else B
     if family == "ddpm":
-        model = DDPM(celeba_namespace(), max_batch=B, conv_math=a.conv_math, nominal_batch=a.nominal_batch)   # configs/church.yml has the same model block
+        model = DDPM(celeba_namespace(), max_batch=max_b, conv_math=a.conv_math, nominal_batch=a.nominal_batch)   # configs/church.yml has the same model block
     else:
-        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=B, conv_math=a.conv_math, nominal_batch=a.nominal_batch)
+        model = i_DDPM("AFHQ" if family == "afhq" else "IMAGENET", max_batch=max_b, conv_math=a.conv_math, nominal_batch=a.nominal_batch)
     model.setattr_layers(1)                     # get_h_num = 1
     cpu_sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
