@@ -92,8 +92,12 @@ def load():
         return _lib
     path = LIB_PATH
     if os.environ.get("ASYRP_LIBRARY") == "bench":
-        # explicit opt-in for A/B runs: the profiling build honours the ASYRP_* kernel switches, the product library reads none
+        # explicit opt-in for A/B runs: the profiling build honours the ASYRP_* kernel switches, the product library reads none.
+        # Said out loud, so that a variable left over in a shell cannot silently change which kernels a product run executes.
+        import warnings
         path = BENCH_LIB_PATH
+        warnings.warn(f"ASYRP_LIBRARY=bench: loading the PROFILING build {path} in place of the product library; it honours the "
+                      "ASYRP_* kernel A/B switches of the environment", RuntimeWarning, stacklevel=2)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: the Asyrp HIP engine has no CPU/PyTorch fallback. "

@@ -145,7 +145,9 @@ def edit_sweep(model, x_T, betas, hs_coeffs, batched=True, **kw):
     batched (round 5): the tuples are independent of one another, so they run as BATCH ENTRIES -- x_T repeated per tuple, one
     coefficient tuple per image (asyrp_run_edit with a per-image table), in chunks of the model's max_batch (<= 128 images) -- instead
     of one engine pass per tuple as the reference loops; every image's bits equal those of the per-tuple pass (tested).  With B
-    images and K tuples this is ceil(B K / max_batch) passes instead of K (a 9-point strength sweep of one image: 1 pass, not 9)."""
+    images and K tuples this is ceil(B K / max_batch) passes instead of K (a 9-point strength sweep of one image: 1 pass, not 9).
+    Deterministic generation only: with an eta = 1 tail (t_addnoise > 0, noise supplied or drawn) or want_latent=True the sweep runs
+    the reference's one pass per tuple, so seeded runs consume the generator exactly as K separate calls do."""
     hs_coeffs = [tuple(hc) for hc in hs_coeffs]
     B, K = x_T.shape[0], len(hs_coeffs)
     index = kw.get("index", 0)
@@ -153,7 +155,12 @@ def edit_sweep(model, x_T, betas, hs_coeffs, batched=True, **kw):
     if not batched or K <= 1 or index is None or index < 0 or cap < 2 * B or len({len(hc) for hc in hs_coeffs}) != 1 \
             or len(hs_coeffs[0]) != index + 2:
         return [run_edit(model, x_T, betas, invert=False, hs_coeff=hc, **kw) for hc in hs_coeffs]
-    if kw.get("noise") is not None:          # the eta = 1 tail draws / takes noise per batch entry: keep the reference's per-tuple passes
+    from .sampler import count_noise_steps, timestep_seq
+    stochastic = count_noise_steps(timestep_seq(kw.get("n_gen", 40), kw.get("t_0", 999))[0], kw.get("t_addnoise", 0)) > 0
+    if kw.get("noise") is not None or stochastic or kw.get("want_latent"):
+        # keep the reference's per-tuple passes where batching would change what a caller observes: an eta = 1 tail takes / draws
+        # its noise per pass (a batched draw would consume the generator in another order), and want_latent makes run_edit
+        # return an (x_edit, x_T) pair per pass
         return [run_edit(model, x_T, betas, invert=False, hs_coeff=hc, **kw) for hc in hs_coeffs]
     per_call = cap // B                        # tuples per engine call
     out = []

@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(CI_NT, 2) conv_in_kernel(const GemmArgs p) {
 // left is the store stream.
 //   A: every lane gathers its own fragments from the fp32 halo in LDS (4 row blocks x 8 values) and splits them in registers.
 //   B: the lane's 8 weights per column block come from the fp32 [tap][3][Cout] image (L2-hot), scaled by 2^10 before the split
-//      (the split's lo term stays normal, as for every other weight image), undone by alpha = 2^-10 in the epilogue.
+//      (the split's lo term stays normal, as for every other weight image), undone by its inverse in the epilogue; the power of two comes
+//      from max|w| at upload (GemmArgs.cin_wmul; 2^10 for PyTorch-default conv_in weights, |w| < 0.2).
 // Results differ from the fp32 stencil by the dropped x_lo w_lo terms (2^-22 relative per product); batch-invariant bit for bit.
 // =====================================================================================================================
 typedef _Float16 cih8 __attribute__((ext_vector_type(8)));
@@ -164,6 +165,8 @@ __global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs 
   // w[k = 8 kq + j][n] * 2^10, two-term split; the waves of wave row 0 build the two column halves, every wave reads its half per tile
   __shared__ __attribute__((aligned(16))) cih8 bfrag[2 * 4 * 2 * 64];         // [wn][tn][hi | lo][lane]
   const int r16 = lane & 15, kq = lane >> 4;
+  // weight scale: a power of two chosen at upload from max|w| (engine.hip pack_x3's rule), so that no |w| saturates the f16 split
+  const float wmul = p.cin_wmul > 0.f ? p.cin_wmul : 1024.f;
   if (wm == 0) {
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {   // unconditional loads from clamped addresses, zeroed by a select (no divergent branches)
         const int k = 8 * kq + j;
-        const float v = p.w[(long long)(k < 27 ? k : 26) * p.ldb + nn] * 1024.f;
+        const float v = p.w[(long long)(k < 27 ? k : 26) * p.ldb + nn] * wmul;
         wv[j] = (k < 27 && n < Cout) ? v : 0.f;
       }
       cih8 h, l;
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(CIM_NT, 4) conv_in_mfma_kernel(const GemmArgs 
   };
   float* const ep = slabs + wave * (16 * CIM_EP);
   const bool want_stats = (p.stats != nullptr);
-  constexpr float ALPHA = 1.0f / 1024.f;
+  const float ALPHA = 1.0f / wmul;      // exact: a power of two
 
   int t = blockIdx.x;
   if (t < ntiles) load_halo(t);

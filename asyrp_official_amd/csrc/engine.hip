@@ -744,6 +744,8 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
     double fl = 0, by = 0;
     if (c.e->prof_on) gemm_work(g, &fl, &by);
     if (fused) *fused = false;
+    auto xit = c.e->xw.find(wname);     // the scale pack_x3 derived from max|w| of this tensor
+    g.cin_wmul = (xit != c.e->xw.end()) ? xit->second.wscale : 0.f;
     return run_timed(c, 400000 + Cout, fl, by, [&]() { return launch_conv_in(g, c.s); });
   }
   if (sc0 && c.e->math != MATH_F16X3) {   // fused shortcut exists only in the f16x3 family
@@ -2797,7 +2799,7 @@ int asyrp_op_conv2d(int device, const float* x0, int C0, const float* x1, int C1
       g.wpk = xg;
     }
     if (tile == XT_CONV_IN) {   // the first-convolution stencil (conv_in.hip): fp32 weights [tap][Cin][Cout] = `wp`
-      g.tile = 0; g.alpha = 1.f;
+      g.tile = 0; g.alpha = 1.f; g.cin_wmul = wscale;
       if (!conv_in_supported(g)) {
         for (void* p : tmp) (void)hipFree(p);
         return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel (3 input channels, 3x3, no prologue / residual / channel vector)");
@@ -2902,7 +2904,7 @@ int asyrp_op_conv2d_stats(int device, const float* x, int Cin, int B, int H, int
     float* wp;
     TRY(dalloc((size_t)ksize * ksize * Cin * Cout, &wp));
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(256), dim3(256), 0, s, weight, wp, Cout, Cin, ksize * ksize);
-    g.w = wp; g.ldb = Cout; g.tile = 0; g.alpha = 1.f;
+    g.w = wp; g.ldb = Cout; g.tile = 0; g.alpha = 1.f; g.cin_wmul = wscale;
     if (!conv_in_supported(g)) {
       for (void* p : tmp) (void)hipFree(p);
       return fail(ASYRP_EINVAL, "shape not covered by the conv_in kernel");

@@ -45,6 +45,8 @@ struct GemmArgs {
   int rups;                       // residual is at half resolution: read pixel (oy>>1, ox>>1) of a (Hout/2 x Wout/2) tensor
                                   //   (nearest x2 of the skip path inside an iDDPM ResBlock(up=True), improved_ddpm/unet.py:281-283)
   float alpha;
+  float cin_wmul;                 // conv_in_mfma_kernel: the power of two its weights are multiplied by before the f16 split (max|w| * cin_wmul in
+                                  //   [1024, 2048), as for every other weight image); 0 = 1024
   float* out; int ldo; long long o_zo, o_zi;
   int ZI, Z;
   int tile;                       // 0 = auto, else TILE_* / XT_* id

@@ -90,6 +90,10 @@ class Engine:
         self.bott_ch = cfg.ch * cfg.ch_mult[cfg.n_levels - 1]      # both families end the encoder at ch * ch_mult[-1]
         self.bott_res = cfg.resolution >> (cfg.n_levels - 1)
 
+    def __repr__(self):
+        return (f"Engine(device=cuda:{self.device_index}, max_batch={self.max_batch}, resolution={self.resolution}, "
+                f"library={getattr(self.lib, '_asyrp_path', '?')})")
+
     def close(self):
         if self.h:
             self.lib.asyrp_destroy(self.h)

@@ -470,7 +470,9 @@ def test_edit_sweep_batches_the_tuples_and_keeps_their_order(monkeypatch):
     assert [c[0] for c in calls] == [6, 2]                     # 3 tuples x 2 images in the first call, the last tuple alone
     assert isinstance(calls[0][1][0], tuple) and len(calls[0][1]) == 6 and calls[0][1][0] == calls[0][1][1] != calls[0][1][2]
     assert len(got) == 4 and all(torch.equal(g, w) for g, w in zip(got, want))
-    for kwargs, n_calls in ((dict(batched=False), 4), (dict(noise=torch.zeros(1)), 4)):
+    # per-tuple fallbacks: asked for, supplied noise, an eta = 1 tail whose noise would be DRAWN (a batched draw consumes the
+    # generator in another order), want_latent (run_edit then returns a pair per pass)
+    for kwargs, n_calls in ((dict(batched=False), 4), (dict(noise=torch.zeros(1)), 4), (dict(t_addnoise=300), 4), (dict(want_latent=True), 4)):
         calls.clear()
         got = cache.edit_sweep(M(), x_T, None, tuples, n_gen=4, **kwargs)
         assert len(calls) == n_calls and all(torch.equal(g, w) for g, w in zip(got, want))
