@@ -19,12 +19,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+sys.path.insert(0, GOLDEN)
+import compact  # noqa: E402  (tests/golden/compact.py: which arrays are stored whole, which as samples, the shared DeltaBlock weights)
+
+
 def load_golden(name):
-    z = np.load(os.path.join(GOLDEN, name))
-    return {k: torch.from_numpy(z[k]) for k in z.files}
+    """name -> tensor, or a `compact.Sampled` comparison target (assert_close / err_stats compare its stored positions)."""
+    return compact.load(os.path.join(GOLDEN, name))
 
 
 def assert_close(got, want, rtol=RTOL, atol=ATOL, what=""):
+    if isinstance(want, compact.Sampled):     # a reference tensor of which one element in 16 is stored: compare those positions
+        got, want, what = want.take(got.detach().float().cpu()), want.values, what + " [1/16 sample]"
     got, want = got.detach().float().cpu(), want.detach().float().cpu()
     assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
     err = (got - want).abs()

@@ -33,7 +33,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = os.environ.get("ASYRP_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
 
+import compact  # noqa: E402  (storage policy: sampled comparison targets, shared DeltaBlock weights)
 from oracle.weights import (CELEBA, SMALL, ddpm_param_shapes, hash_normal, hash_uniform,  # noqa: E402
                             synthetic_state_dict)
 
@@ -109,7 +111,7 @@ def run_small(out):
                                            t_edit=t_edit, hs_coeff=(1.0, 1.0), **kw)
         g["edit.x_edit"] = xx
     g["input.x"] = x
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -132,7 +134,7 @@ def run_celeba(out):
                                        b=betas, sampling_type="ddim", eta=0.0, index=0, t_edit=500,
                                        hs_coeff=(1.0, 1.0))
         g["step_gen.xt_next"], g["step_gen.x0_t"] = xn, x0t
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -199,7 +201,7 @@ def run_iddpm_small(out):
                                            t_edit=t_edit, hs_coeff=(1.0, 1.0), **kw)
         g["edit.x_edit"] = xx
     g["input.x"] = x
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -216,7 +218,7 @@ def run_iddpm_small2(out):
         t = torch.ones(2) * 555.0
         et, em, dh, mh = m(x, t, y=torch.tensor([3, 7]), index=0, t_edit=500, hs_coeff=(1.0, 0.8))
         g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -248,7 +250,7 @@ def run_afhq(out):
         mg.load_state_dict(sd, strict=True)
         et_g, em_g, _, _ = mg.eval()(x, t, index=0, t_edit=444, hs_coeff=(1.0, 1.0))
         assert torch.equal(et_g, et) and torch.equal(em_g, em), "guided_diffusion UNet differs from improved_ddpm UNet"
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -281,7 +283,7 @@ def run_slerp(out):
                                              sampling_type="ddim", learn_sigma=ls, eta=0.0, index=0, t_edit=500,
                                              hs_coeff=(0.7, 1.0), delta_h=dh_in)
             g[f"{name}.step.xt_next"], g[f"{name}.step.x0_t"] = xn, x0t
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -375,7 +377,7 @@ def run_config1(out, tame=1.0):
     for k, v in sd.items():                               # the shipped DeltaBlock itself: /root/reference is not on the GPU box
         if k.startswith("layer_0."):
             g["param." + k] = v.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -400,7 +402,7 @@ def run_config1_tame(out, tame=0.01):
         for i, j in zip(reversed(seq), reversed(seq_next)):
             x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=500, hs_coeff=(1.0, 1.0), **kw)
         g["x_edit"] = x.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -442,7 +444,7 @@ def run_config3(out):
     for k, v in sd.items():
         if k.startswith("layer_0."):
             g["param." + k] = v.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -492,7 +494,7 @@ def run_train_small(out):
         g[f"{tag}.x0_t"], g[f"{tag}.xt_next"] = x0t.detach().clone(), xn.detach().clone()
         for k, p_ in mi.layer_0.named_parameters():
             g[f"{tag}.grad.layer_0.{k}"] = (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -533,7 +535,7 @@ def run_vendored_samplers(out):
                 g[f"{name}.t{tv}.ddim.sample"], g[f"{name}.t{tv}.ddim.pred_xstart"] = ds["sample"].clone(), ds["pred_xstart"].clone()
                 rs = diff.ddim_reverse_sample(model, x, t, clip_denoised=False, eta=0.0)
                 g[f"{name}.t{tv}.ddim_reverse.sample"] = rs["sample"].clone()
-    np.savez_compressed(out, **{k: v.numpy() for k, v in g.items()})
+    compact.save(out, {k: v.numpy() for k, v in g.items()})
     print("wrote", out, sorted(g)[:6], "...", len(g), "tensors")
 
 
@@ -575,7 +577,7 @@ def run_imagenet(out):
     g["fwd_dual.et"], g["fwd_dual.et_mod"], g["fwd_dual.delta_h"], g["fwd_dual.middle_h"] = et, em, dh, mh
     g["probe.x"] = x[0, 0, 0, :8].clone()
     g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -609,7 +611,7 @@ def run_config4(out):
     for k, v in sd.items():                               # the shipped DeltaBlock itself: /root/reference is not on the GPU box
         if k.startswith("layer_0."):
             g["param." + k] = v.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -652,7 +654,7 @@ def run_config3_full(out):
     for k, v in sd.items():
         if k.startswith("layer_0."):
             g["param." + k] = v.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -678,7 +680,7 @@ def run_imagenet_step(out):
     g["step.xt_next"], g["step.x0_t"], g["step.delta_h"] = xn, x0t, dh
     g["probe.x"] = x[0, 0, 0, :8].clone()
     g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -709,7 +711,7 @@ def run_config1_b2(out):
     for k, v in sd.items():
         if k.startswith("layer_0."):
             g["param." + k] = v.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -739,7 +741,7 @@ def run_config4_full(out):
         for i, j in zip(reversed(seq), reversed(seq_next)):
             x, _, _, _ = denoising_step(x, t=one * i, t_next=one * j, eta=0.0, index=0, t_edit=370, hs_coeff=(1.0, 1.0), **kw)
         g["x_edit"] = x.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -776,7 +778,7 @@ def run_imagenet_traj(out):
                 first = False
         g["x_edit"] = x.clone()
     g["probe.w"] = sd["out.2.weight"].reshape(-1)[:8].clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
@@ -804,7 +806,7 @@ def run_afhq_b2(out):
         xm = torch.cat([hash_normal("afhqb2.xma", (1, 3, 256, 256), seed=23), hash_normal("afhqb2.xmb", (1, 3, 256, 256), seed=24)])
         xn, _, dh, _ = denoising_step(xm, t=two * 768, t_next=two * 742, index=0, t_edit=444, hs_coeff=(1.0, 1.0), **kw)
         g["gen768.xt_next"], g["gen768.delta_h"] = xn.clone(), dh.clone()
-    np.savez_compressed(out, **{k: v.numpy().astype(np.float32) for k, v in g.items()})
+    compact.save(out, {k: v.numpy().astype(np.float32) for k, v in g.items()})
     print("wrote", out, {k: tuple(v.shape) for k, v in g.items()})
 
 
