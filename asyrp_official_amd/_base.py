@@ -182,8 +182,13 @@ class HipUNet(nn.Module):
         with slot.lock:
             if slot.engine is None or slot.sig != sig:
                 if slot.engine is not None:
+                    # a larger batch / another DeltaBlock count: the SAME Engine object gets a new native handle, so that references a
+                    # caller took earlier (`eng = model.engine()`) stay valid instead of pointing at a destroyed engine
                     slot.engine.close()
-                slot.engine, slot.uploaded = Engine(src._make_cfg(src._n_delta), sig[2], idx), {}
+                    slot.engine.__init__(src._make_cfg(src._n_delta), sig[2], idx)
+                else:
+                    slot.engine = Engine(src._make_cfg(src._n_delta), sig[2], idx)
+                slot.uploaded = {}
                 slot.sig = sig
                 slot.engine.set_temb_freqs(src._temb_freqs())
                 if getattr(src, "_betas", None) is not None:

@@ -82,7 +82,8 @@ def _serialised(fn):
 class Engine:
     def __init__(self, cfg, max_batch, device_index):
         self.lib = _lib.load()
-        self.lock = threading.RLock()
+        if not hasattr(self, "lock"):            # re-initialised in place when the owner grows it (HipUNet.engine): keep the lock
+            self.lock = threading.RLock()
         self.cfg, self.max_batch, self.device_index = cfg, int(max_batch), int(device_index)
         self.h = C.c_void_p()
         _lib.check(self.lib.asyrp_create(C.byref(self.h), C.byref(cfg), self.max_batch, self.device_index))

@@ -169,6 +169,22 @@ def test_engine_calls_from_concurrent_threads_are_serialised_and_deterministic(m
         _same(got[i], want[i], f"thread {i}")
 
 
+def test_engine_reference_survives_a_larger_batch():
+    """A batch above max_batch re-creates the native engine; the Engine OBJECT a caller holds must stay usable (round 6: bench.py held
+    `eng = model.engine()` across such a call and then drove a destroyed handle)."""
+    sd = synthetic(SMALL, 1, seed=11)
+    m = hip_model(SMALL, sd, 1, max_batch=1)
+    x1, t1 = _x(1, seed=71), torch.full((1,), 701.0, device="cuda")
+    eng = m.engine()
+    want = m(x1, t1, **EDIT)
+    x3, t3 = _x(3, seed=72), torch.full((3,), 701.0, device="cuda")
+    big = m(x3, t3, **EDIT)                               # 3 > max_batch = 1: the engine grows
+    assert m.engine() is eng and eng.max_batch == 3 and m.max_batch == 3
+    got = eng.unet_forward(x1, t1, index=0, apply_edit=True, hs_coeff=(1.0, 1.0))
+    _same(got, want, "engine reference after growth")
+    _same(m(x3[2:], t3[2:], **EDIT), tuple(o[2:] if o is not None else None for o in big), "row 2 alone after growth")
+
+
 need2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
 
 

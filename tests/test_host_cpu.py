@@ -481,3 +481,40 @@ def test_edit_sweep_batches_the_tuples_and_keeps_their_order(monkeypatch):
     got = cache.edit_sweep(M(), x_T, None, tuples, n_gen=4)
     assert len(calls) == 4 and all(torch.equal(g, w) for g, w in zip(got, want))
 
+
+
+def test_compact_fixture_storage_roundtrip(tmp_path):
+    """tests/golden/compact.py: a fixture written under the storage policy reads back as the same values -- sampled keys at the hashed
+    positions (one per run of 16 elements, reproducible from the key alone), whole keys untouched, the shared DeltaBlock weights
+    merged back under `param.*` -- and assert_close / err_stats compare a Sampled target at exactly those positions."""
+    import numpy as np
+    from conftest import assert_close
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import compact
+    from util_models import err_stats
+    name = "config4_church_gothic.npz"
+    rng = np.random.default_rng(0)
+    full = {k: rng.standard_normal((1, 3, 32, 32)).astype(np.float32) for k in compact.SAMPLED[name]}
+    full["gen999.delta_h"] = rng.standard_normal((1, 8, 4, 4)).astype(np.float32)
+    full["param.layer_0.conv1.weight"] = rng.standard_normal((4, 4, 1, 1)).astype(np.float32)
+    compact.save(str(tmp_path / name), full)
+    assert (tmp_path / compact.PARAM_FILE[name]).exists()
+    compact.save(str(tmp_path / name), full)                              # second fixture of the same checkpoint: weights must agree
+    g = compact.load(str(tmp_path / name))
+    assert torch.equal(g["gen999.delta_h"], torch.from_numpy(full["gen999.delta_h"]))
+    assert torch.equal(g["param.layer_0.conv1.weight"], torch.from_numpy(full["param.layer_0.conv1.weight"]))
+    for k in compact.SAMPLED[name]:
+        s_ = g[k]
+        assert isinstance(s_, compact.Sampled) and s_.shape == (1, 3, 32, 32) and s_.values.numel() == 3 * 32 * 32 // 16
+        idx = compact.sample_index(3 * 32 * 32, k)
+        assert np.array_equal(idx // 16, np.arange(idx.size)) and len({int(i) % 16 for i in idx}) > 8      # one per run, spread
+        assert torch.equal(s_.values, torch.from_numpy(full[k].reshape(-1)[idx]))
+        t = torch.from_numpy(full[k])
+        assert_close(t, s_)
+        assert err_stats(t, s_)["max_abs"] == 0.0
+        bad = t.clone().reshape(-1)
+        bad[int(idx[5])] += 1.0                                           # a stored position: must be seen
+        with pytest.raises(AssertionError):
+            assert_close(bad.reshape(t.shape), s_)
+    with pytest.raises(AssertionError):                                  # other weights under the same checkpoint name: refused
+        compact.save(str(tmp_path / name), dict(full, **{"param.layer_0.conv1.weight": full["param.layer_0.conv1.weight"] + 1}))
