@@ -49,7 +49,7 @@ traffic() {   # traffic <tag> [bench args]   -> gpurun_out/<tag>/traffic_familie
   local t=$1; shift; local o=$GRAFT_REPO_ROOT/gpurun_out/$t; mkdir -p $o
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $o/$C -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-parity-check "$@" > $o/$C.log 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-parity-check --no-other-configs "$@" > $o/$C.log 2>&1)
   done
   python scripts/traffic_summary.py $o $LIB $o/traffic_families.json \
     "bench.py --steps 1 --warmup 0 --no-parity-check $* (one whole edit + the 9 phase-timing steps), every kernel" | head -30
@@ -59,11 +59,11 @@ traffic() {   # traffic <tag> [bench args]   -> gpurun_out/<tag>/traffic_familie
 case $WHAT in
 visit)
   suite -x -s
-  bench_line $OUT/bench.json --steps 2 --warmup 1 --no-cpu-baseline "$@" ;;
+  bench_line $OUT/bench.json --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs "$@" ;;
 round)
   suite
   bench_line $OUT/bench.json --steps 1 --warmup 1
-  kernel_stats $OUT/prof --steps 1 --warmup 0 --no-cpu-baseline ;;
+  kernel_stats $OUT/prof --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs ;;
 evidence)
   suite
   # traffic first: bench.py pastes it only when its stamp matches the loaded library
@@ -74,14 +74,23 @@ evidence)
   cp profiles/traffic_families_celeba_b32_*.json $OUT/ 2>/dev/null
   tail -14 $OUT/traffic_f16x3.log
   bench_line $OUT/bench_driver_cmd.json --steps 20 --warmup 5
-  kernel_stats $OUT/prof --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check
+  kernel_stats $OUT/prof --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-other-configs
   mv $OUT/prof.json $OUT/bench_under_rocprof.json 2>/dev/null
-  bench_line $OUT/bench_fastmode_f16.json --conv-math f16 --steps 10 --warmup 3
+  bench_line $OUT/bench_fastmode_f16.json --conv-math f16 --steps 10 --warmup 3 --no-other-configs
   for cfg in afhq imagenet church; do bench_line $OUT/bench_$cfg.json --config $cfg --steps 2 --warmup 1 --no-cpu-baseline; done
   bench_line $OUT/bench_b1.json --batch 1 --steps 5 --warmup 1 --no-cpu-baseline
   (ASYRP_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 --batch 4 --no-kernel-events --no-cpu-baseline 2> $OUT/bench_selflaunch_2rank_gloo_dryrun.err | tail -1) > $OUT/bench_selflaunch_2rank_gloo_dryrun.json
   cut -c1-200 $OUT/bench_selflaunch_2rank_gloo_dryrun.json
   find gpurun_out/$TAG gpurun_out/${TAG}_traffic_f16x3 gpurun_out/${TAG}_traffic_f16 -name '*.csv' -size +1M -delete ;;
+evidence-core)      # the three files the driver's line is judged with: traffic (PMC), the driver's command, its rocprofv3 kernel stats
+  traffic ${TAG}_traffic_f16x3 > $OUT/traffic_f16x3.log 2>&1
+  cp gpurun_out/${TAG}_traffic_f16x3/traffic_families.json profiles/traffic_families_celeba_b32_f16x3.json 2>/dev/null
+  cp profiles/traffic_families_celeba_b32_f16x3.json $OUT/ 2>/dev/null
+  tail -14 $OUT/traffic_f16x3.log
+  bench_line $OUT/bench_driver_cmd.json --steps 20 --warmup 5
+  kernel_stats $OUT/prof --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-other-configs
+  mv $OUT/prof.json $OUT/bench_under_rocprof.json 2>/dev/null
+  find gpurun_out/$TAG gpurun_out/${TAG}_traffic_f16x3 -name '*.csv' -size +1M -delete ;;
 traffic)
   traffic $TAG "$@" ;;
 pmc)
@@ -90,7 +99,7 @@ pmc)
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"; do
     P=$((P+1))
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pass$P -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-parity-check > $OUT/pass$P.log 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-parity-check --no-other-configs > $OUT/pass$P.log 2>&1)
     tail -n 2 $OUT/pass$P.log | cut -c1-200
   done
   python scripts/pmc_summary.py $OUT $LIB $OUT/pmc_families.json
@@ -133,7 +142,7 @@ ab)
     for e in "X=0" "$@"; do
       i=$((i+1))
       echo "== $e"
-      (env $e timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>> $OUT/err.txt | tail -1) > $OUT/run_$i.json
+      (env $e timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs 2>> $OUT/err.txt | tail -1) > $OUT/run_$i.json
       python - "$OUT/run_$i.json" <<'PY'
 import json, sys
 try:
