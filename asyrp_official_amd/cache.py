@@ -43,7 +43,9 @@ def inversion_trace(model, x0, betas, *, n_inv=40, t_0=999, learn_sigma=False, w
     inversion of x0 over n_inv timesteps yielding (t_next, x_{t_next}, x0_t) for EVERY step, so the caller can feed both to
     LPIPS exactly as the reference does (`loss_fn_alex(x, x0)`, `loss_fn_alex(x0_t, x0)`).  The walk is cut into windows of
     `window` steps (asyrp_run_inversion taps) so n_inv = 1000 needs 2 x window x B images of device memory, not 2000 x B."""
+    from .data_parallel import unwrap
     from .sampler import timestep_seq
+    model = unwrap(model)
     model.set_schedule(betas)
     eng = model._ready_engine(x0)
     seq = timestep_seq(n_inv, t_0)[0]
@@ -151,7 +153,7 @@ def edit_sweep(model, x_T, betas, hs_coeffs, batched=True, **kw):
     hs_coeffs = [tuple(hc) for hc in hs_coeffs]
     B, K = x_T.shape[0], len(hs_coeffs)
     index = kw.get("index", 0)
-    cap = min(int(getattr(model, "max_batch", B)), 128)
+    cap = min(int(getattr(getattr(model, "module", model), "max_batch", B)), 128)
     if not batched or K <= 1 or index is None or index < 0 or cap < 2 * B or len({len(hc) for hc in hs_coeffs}) != 1 \
             or len(hs_coeffs[0]) != index + 2:
         return [run_edit(model, x_T, betas, invert=False, hs_coeff=hc, **kw) for hc in hs_coeffs]

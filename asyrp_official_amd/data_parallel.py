@@ -12,6 +12,9 @@ that share its batch):
   * `asyrp_official_amd.denoising_step(..., models=<either wrapper>)` — B2 through the wrapper: the batch is scattered over the
     wrapper's `device_ids`, each chunk runs the FUSED step (`asyrp_ddim_step`) on its device's engine in its own host thread, the
     four results are gathered on `output_device` (`sharded_step` below).  No replicate at all.
+  * `asyrp_official_amd.run_edit(<either wrapper>, x0, betas, ...)` — both loops through the wrapper: ONE scatter of x0 (and of the
+    eta = 1 noise / per-image coefficient tuples), each chunk runs the whole inversion + generation (`asyrp_run_edit`) on its device's
+    engine in its own host thread — one long GIL-free C call per device — and ONE gather of x_edit (`sharded_edit` below).
 
 The fast multi-GPU form stays one process per GPU (`sampler.run_edit_sharded`): no per-step scatter / gather,
 no GIL, one RCCL all-gather per edit.
@@ -73,3 +76,36 @@ def sharded_step(models, model, xt, *, noise=None, delta_h=None, **step):
     outs = parallel_apply([run] * n, list(zip(xs, nz, dh)), devices=ids)
     xt_next, x0_t, dh_out, mid = gather(outs, models.output_device)
     return xt_next, x0_t, (delta_h if delta_h is not None else dh_out), mid
+
+
+def unwrap(model):
+    """The engine-backed UNet behind a DataParallel wrapper (or the model itself)."""
+    m = model.module if isinstance(model, torch.nn.DataParallel) else model
+    if not isinstance(m, HipUNet):
+        raise TypeError(f"expected an asyrp_official_amd UNet (optionally wrapped in DataParallel), got {type(m).__name__}")
+    return m
+
+
+def sharded_edit(models, model, x0, seq_inv, seq_gen, *, noise=None, hs_coeff=(1.0, 1.0), want_latent=False, **edit):
+    """Both loops (`Engine.run_edit`) of the batch `x0`, scattered over `models.device_ids`: one scatter, one whole edit per chunk,
+    device and host thread, one gather.  `noise` is [n_eta_steps, B, 3, R, R] (scattered along its batch dimension); per-image
+    `hs_coeff` tuples are split with the batch.  Returns x_edit (and x_T) on `models.output_device`."""
+    ids = wrapper_devices(models)
+    xs = scatter(x0, ids)
+    n = len(xs)
+    ids = ids[:n]
+    nz = scatter(noise, ids, dim=1) if noise is not None else (None,) * n
+    per_image = len(hs_coeff) > 0 and isinstance(hs_coeff[0], (tuple, list))
+    if per_image and len(hs_coeff) != x0.shape[0]:
+        raise ValueError(f"per-image hs_coeff must hold {x0.shape[0]} tuples")
+    lo, coeffs = 0, []
+    for x in xs:                                                   # the tuples of each chunk's images
+        coeffs.append(list(hs_coeff[lo:lo + x.shape[0]]) if per_image else hs_coeff)
+        lo += x.shape[0]
+
+    def run(x, z, hc):
+        z = z.contiguous() if z is not None else None
+        return model._ready_engine(x).run_edit(x.contiguous(), seq_inv, seq_gen, noise=z, hs_coeff=hc, want_latent=want_latent, **edit)
+
+    outs = parallel_apply([run] * n, list(zip(xs, nz, coeffs)), devices=ids)
+    return gather(outs, models.output_device)

@@ -44,15 +44,20 @@ def count_noise_steps(seq_gen, t_addnoise):
 def run_edit(model, x0, betas, *, n_inv=40, n_gen=40, t_0=999, t_edit=500, t_addnoise=0, index=0,
              hs_coeff=(1.0, 1.0), learn_sigma=False, noise=None, want_latent=False, invert=True):
     """x0 [B,3,R,R] (GPU) -> x_edit (and x_T).  `noise` = [n_eta_steps,B,3,R,R] for the eta=1 tail."""
+    from . import data_parallel
+    wrapper, model = model, data_parallel.unwrap(model)       # `model` may be the reference's DataParallel wrapper (diffusion_latent.py:591)
     model.set_schedule(betas)
-    eng = model._ready_engine(x0)
     seq_inv = timestep_seq(n_inv, t_0)[0] if invert else []
     seq_gen = timestep_seq(n_gen, t_0)[0]
     need = count_noise_steps(seq_gen, t_addnoise)
     if need and noise is None:
         noise = torch.randn((need,) + tuple(x0.shape), device=x0.device, dtype=torch.float32)
-    return eng.run_edit(x0, seq_inv, seq_gen, t_edit=t_edit, t_addnoise=t_addnoise, index=index, hs_coeff=hs_coeff,
-                        learn_sigma=learn_sigma, noise=noise, want_latent=want_latent)
+    kw = dict(t_edit=t_edit, t_addnoise=t_addnoise, index=index, hs_coeff=hs_coeff, learn_sigma=learn_sigma, noise=noise,
+              want_latent=want_latent)
+    if x0.shape[0] > 1 and data_parallel.wrapper_devices(wrapper):
+        # several devices behind the wrapper: one scatter, the whole edit per device in its own host thread, one gather
+        return data_parallel.sharded_edit(wrapper, model, x0, seq_inv, seq_gen, **kw)
+    return model._ready_engine(x0).run_edit(x0, seq_inv, seq_gen, **kw)
 
 
 @torch.no_grad()

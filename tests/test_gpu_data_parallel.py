@@ -142,6 +142,36 @@ def test_denoising_step_through_the_wrapper_shards_the_batch(model):
     assert got[2] is dh and all(torch.equal(g, v) for g, v in zip(got, want))
 
 
+def test_run_edit_through_the_wrapper_is_one_scatter_one_edit_per_device_one_gather(model):
+    """`run_edit(<DataParallel wrapper>, x0, betas, ...)`: the batch is scattered once, every chunk runs BOTH loops on its device's
+    engine in its own host thread, x_edit (and x_T) are gathered once -- bitwise the unwrapped call, incl. the eta = 1 tail with supplied
+    noise (scattered along its batch dimension), per-image coefficient tuples (an editing-strength sweep as batch entries), and
+    cache.edit_sweep / cache.precompute_pairs handed the wrapper as the reference's scripts would."""
+    from asyrp_official_amd import DataParallel, cache, run_edit
+    from asyrp_official_amd.sampler import count_noise_steps, timestep_seq
+    m, _ = model
+    w = DataParallel(m, device_ids=[0, 0])
+    b = osamp.beta_schedule()
+    B = 5
+    x = _x(B, seed=61)
+    kw = dict(n_inv=5, n_gen=6, t_edit=500)
+    want, want_T = run_edit(m, x, b, want_latent=True, **kw)
+    got, got_T = run_edit(w, x, b, want_latent=True, **kw)
+    assert torch.equal(got, want) and torch.equal(got_T, want_T)
+    assert torch.equal(run_edit(w, x[:1], b, **kw), want[:1])                       # a batch of one: the wrapper's first device
+    need = count_noise_steps(timestep_seq(6, 999)[0], 450)
+    assert need >= 2
+    nz = hash_normal("dp.edit.noise", (need, B, 3, 32, 32)).cuda()
+    assert torch.equal(run_edit(w, x, b, t_addnoise=450, noise=nz, **kw), run_edit(m, x, b, t_addnoise=450, noise=nz, **kw))
+    tuples = [(1.0, 0.2 * i) for i in range(B)]                                     # one coefficient tuple per image
+    assert torch.equal(run_edit(w, x, b, hs_coeff=tuples, **kw), run_edit(m, x, b, hs_coeff=tuples, **kw))
+    sweep = cache.delta_interpolation_coeffs(-1.0, 1.0, 3, hs_coeff=(1.0, 1.0))
+    a_, b_ = cache.edit_sweep(w, want_T[:2], b, sweep, n_gen=6, t_edit=500), cache.edit_sweep(m, want_T[:2], b, sweep, n_gen=6, t_edit=500)
+    assert len(a_) == len(b_) == 3 and all(torch.equal(p, q) for p, q in zip(a_, b_))
+    pa, pb = cache.precompute_pairs(w, x[:3], b, n_inv=5), cache.precompute_pairs(m, x[:3], b, n_inv=5)
+    assert all(torch.equal(u, v) for ta, tb in zip(pa, pb) for u, v in zip(ta, tb))
+
+
 def test_engine_calls_from_concurrent_threads_are_serialised_and_deterministic(model):
     """Eight host threads hammer ONE device engine through replicas (what DataParallel does when device ids repeat): every call must
     return the bits of the single-threaded call — the engine recycles its workspace on one in-order stream, so calls take turns."""
