@@ -3,6 +3,7 @@
 // arithmetic op of the hot path is a launch of a kernel from kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -596,7 +597,13 @@ struct Ctx {
   asyrp_engine* e;
   hipStream_t s;
   int B;
-  float* tproj = nullptr;   // [B][tproj_total]
+  float* tproj = nullptr;   // [B][tproj_total], or ONE row shared by the batch (tproj_ld == 0)
+  int tproj_ld = 0;         // row pitch of tproj per image: tproj_total, or 0 when every image reads the same row
+  // asyrp_run_edit knows every timestep of the edit in advance and all images of a batch share it: the timestep embedding and
+  // every block's Linear(swish(temb)) are computed for ALL steps in two launches before the loops (round 6); a step then points
+  // here at its row and unet_core skips its own two launches.  Per row the arithmetic is the per-step launches' (one workgroup
+  // per row in temb_mlp_kernel; a fixed tile and a K-only accumulation order in the projection GEMM), so the bits are the same.
+  const float* tproj_pre = nullptr;
   const float* dh_in = nullptr;   // injected delta-h tensor (NHWC) -> slerp mix instead of the DeltaBlocks
   int coeff_per_image = 0;        // hs_coeff is [B][index + 2]: one tuple per image (batched strength sweeps, asyrp_run_edit)
   int use_mask = 0;
@@ -726,7 +733,7 @@ int conv(Ctx& c, const Act& x0, const Act* x1, const std::string& wname, const s
   if (!g.w) return fail(ASYRP_EKEY, "missing packed weight " + wname);
   g.ldb = ldb_full ? ldb_full : Cout;   // (a launch may use the leading Cout columns of a wider packed weight)
   g.bias = bname.empty() ? nullptr : P(c, bname);
-  g.chan_add = chan_add; g.ld_chan_add = c.e->tproj_total;
+  g.chan_add = chan_add; g.ld_chan_add = c.tproj_ld;
   if (resid) { g.resid = resid->p; g.ldr = resid->C; g.r_zo = resid->per_image(); g.rups = rups; }
   g.alpha = 1.0f;
   g.out = out->p; g.ldo = Cout; g.o_zo = out->per_image();
@@ -888,18 +895,34 @@ int gn(Ctx& c, const Act& x0, const Act* x1, const std::string& prefix, float ep
 
 // every block's Linear(swish(temb)) at once: [B x temb_ch] x [temb_ch x O_total] + bias on the fp32-MFMA GEMM (exact fp32 fma
 // chain per output), one launch per UNet evaluation
-int tproj_gemm(Ctx& c, const float* temb_act) {
+int tproj_gemm(Ctx& c, const float* temb_act, int rows = 0, float* out = nullptr) {
   asyrp_engine* e = c.e;
+  if (rows <= 0) rows = c.B;
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.a0 = temb_act; g.c0 = e->temb_ch; g.lda0 = e->temb_ch;
-  g.Hin = c.B; g.Win = 1; g.Hout = c.B; g.Wout = 1; g.Cin = e->temb_ch; g.Cout = e->tproj_total; g.ks = 1; g.stride = 1;
+  g.Hin = rows; g.Win = 1; g.Hout = rows; g.Wout = 1; g.Cin = e->temb_ch; g.Cout = e->tproj_total; g.ks = 1; g.stride = 1;
   g.w = P(c, "__tproj.weight"); g.ldb = e->temb_ch; g.bT = 1;      // W is [O_total][temb_ch]
   g.bias = P(c, "__tproj.bias");
-  g.alpha = 1.0f; g.out = c.tproj; g.ldo = e->tproj_total; g.ZI = 1; g.Z = 1; g.math = MATH_F32;
+  g.alpha = 1.0f; g.out = out ? out : c.tproj; g.ldo = e->tproj_total; g.ZI = 1; g.Z = 1; g.math = MATH_F32;
   g.tile = TILE_64x64;          // fixed: the rows are the batch, so the tile must not depend on M
   if (!g.w || !g.bias) return fail(ASYRP_EKEY, "missing timestep projection pack");
   return run_gemm(c, g);
+}
+
+// timestep embedding + MLP of `rows` timesteps (t_dev[rows]) and every block's Linear(swish(temb)) for them: the two launches at the
+// head of a UNet evaluation (rows = the batch), or of a whole edit (rows = its steps, asyrp_run_edit).
+// DDPM: get_timestep_embedding [sin|cos] -> temb.dense.0/1 (models/ddpm/diffusion.py:42-60, 477-480); iDDPM: [cos|sin] -> time_embed.0/2
+// (improved_ddpm/nn.py:103-121, unet.py:513-517)
+int timestep_rows(Ctx& c, const float* t_dev, int rows, float* temb, float* temb_act, float* tproj_out) {
+  asyrp_engine* e = c.e;
+  const bool iddpm = e->cfg.family == ASYRP_FAMILY_IDDPM;
+  const char* n0 = iddpm ? "time_embed.0" : "temb.dense.0";
+  const char* n1 = iddpm ? "time_embed.2" : "temb.dense.1";
+  HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, iddpm ? 0 : 1, P(c, std::string(n0) + ".weight"), P(c, std::string(n0) + ".bias"),
+                         P(c, std::string(n1) + ".weight"), P(c, std::string(n1) + ".bias"), e->cfg.ch, e->temb_ch, temb, temb_act, rows,
+                         c.s));
+  return tproj_gemm(c, temb_act, rows, tproj_out);
 }
 
 // Dual-decoder steps run the decoder twice over the SAME skip tensors (models/ddpm/diffusion.py:541-577: h + delta_h and h).
@@ -972,7 +995,7 @@ int conv1_shared(Ctx& c, const std::string& p, const std::string& wname, const s
   }
   TRY(new_act(c, Cout, H, W, h1));
   g.bias = P(c, bname);
-  g.chan_add = chan_add; g.ld_chan_add = e->tproj_total;
+  g.chan_add = chan_add; g.ld_chan_add = c.tproj_ld;
   g.resid = part.p; g.ldr = Cout; g.r_zo = part.per_image();
   g.out = h1->p;
   h1->st_nblk = gemm_mblocks(g);
@@ -1300,7 +1323,7 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
   e->pool.put(sc1); e->pool.put(sh1);
   // h = GN(h) * (1 + scale) + shift, (scale, shift) = chunk(Linear(SiLU(emb)), 2)  (:290-294)
   const float* film = c.tproj + e->tproj_off.at(p);
-  TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, e->tproj_total, c.tape ? &mr2 : nullptr));
+  TRY(gn(c, h1, nullptr, p + ".out_layers.0", EPS_I, &sc2, &sh2, film, film + Cout, c.tproj_ld, c.tape ? &mr2 : nullptr));
   if (c.tape) {
     if (L.mode == 1) return fail(ASYRP_EINVAL, "down-sampling ResBlock inside the decoder");
     TapeRes t;
@@ -1309,7 +1332,7 @@ int resblock_i(Ctx& c, const asyrp_engine::Layer& L, const Act& x0, const Act* x
     t.h1 = h1; t.sc1 = sc1; t.sh1 = sh1; t.mr1 = mr1; t.sc2 = sc2; t.sh2 = sh2; t.mr2 = mr2;
     t.Cout = Cout; t.shortcut = (Cin != Cout); t.mode = L.mode;
     t.n1 = ".in_layers.0"; t.c1 = ".in_layers.2"; t.n2 = ".out_layers.0"; t.c2 = ".out_layers.3"; t.sk = ".skip_connection";
-    t.film = film; t.ld_film = e->tproj_total;
+    t.film = film; t.ld_film = c.tproj_ld;
     c.tape->order.push_back({0, (int)c.tape->res.size()});
     c.tape->res.push_back(t);
     e->pool.put(mr1); e->pool.put(mr2);
@@ -1453,25 +1476,29 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   const asyrp_config& cf = e->cfg;
   et_mod->p = nullptr;
   last_delta->p = nullptr;
-  float *temb, *temb_act;
-  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
-  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
-  TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
-  // timestep_embedding [cos|sin] (nn.py:103-121) -> time_embed = Linear, SiLU, Linear (:513-517); every block's
-  // emb_layers = Linear(SiLU(emb)) in one launch
-  HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 0, P(c, "time_embed.0.weight"), P(c, "time_embed.0.bias"),
-                         P(c, "time_embed.2.weight"), P(c, "time_embed.2.bias"), cf.ch, e->temb_ch, temb, temb_act, c.B,
-                         c.s));
-  TRY(tproj_gemm(c, temb_act));
+  const bool pre = c.tproj_pre && !c.tape;      // this step's row was computed before the loops (asyrp_run_edit)
+  float *temb = nullptr, *temb_act = nullptr;
+  if (pre) {
+    c.tproj = const_cast<float*>(c.tproj_pre);
+    c.tproj_ld = 0;
+  } else {
+    TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
+    TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
+    TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
+    c.tproj_ld = e->tproj_total;
+    // timestep_embedding [cos|sin] (nn.py:103-121) -> time_embed = Linear, SiLU, Linear (:513-517); every block's
+    // emb_layers = Linear(SiLU(emb)) in one launch
+    TRY(timestep_rows(c, t_dev, c.B, temb, temb_act, c.tproj));
+  }
   Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;
-  e->pool.put(temb);
+  if (temb) e->pool.put(temb);
   // training forward: the pool HOLDS (instead of recycling) exactly what the backward pass reads -- swish(temb), the skip
   // tensors, the bottleneck h, the timestep projections and everything the DeltaBlock + decoder #2 window returns; the encoder's
   // and decoder #1's intermediates are recycled as in inference
   e->pool.defer = (tape != nullptr);
-  e->pool.put(temb_act);
+  if (temb_act) e->pool.put(temb_act);
   e->pool.defer = false;
   std::vector<Act> hs;
   Act xin;
@@ -1520,7 +1547,7 @@ int unet_core_iddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, 
   c.skip_part.clear();
   e->pool.defer = (tape != nullptr);                 // skips and timestep projections: read by the backward pass
   for (auto& a : hs) drop(c, a);
-  e->pool.put(c.tproj);
+  if (!pre) e->pool.put(c.tproj);
   e->pool.defer = false;
   c.tproj = nullptr;
   return 0;
@@ -1544,23 +1571,27 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   et_mod->p = nullptr;
   last_delta->p = nullptr;
   // timestep embedding + every block's Linear(swish(temb)) in one launch
-  float *temb, *temb_act;
-  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
-  TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
-  TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
-  HIPCHK(launch_temb_mlp(t_dev, e->d_freqs, e->n_freqs, 1, P(c, "temb.dense.0.weight"), P(c, "temb.dense.0.bias"),
-                         P(c, "temb.dense.1.weight"), P(c, "temb.dense.1.bias"), cf.ch, e->temb_ch, temb, temb_act,
-                         c.B, c.s));
-  TRY(tproj_gemm(c, temb_act));
+  const bool pre = c.tproj_pre && !c.tape;      // this step's row was computed before the loops (asyrp_run_edit)
+  float *temb = nullptr, *temb_act = nullptr;
+  if (pre) {
+    c.tproj = const_cast<float*>(c.tproj_pre);
+    c.tproj_ld = 0;
+  } else {
+    TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb));
+    TRY(e->pool.get((size_t)c.B * e->temb_ch, &temb_act));
+    TRY(e->pool.get((size_t)c.B * e->tproj_total, &c.tproj));
+    c.tproj_ld = e->tproj_total;
+    TRY(timestep_rows(c, t_dev, c.B, temb, temb_act, c.tproj));
+  }
   Tape* const tape = c.tape;     // recording is limited to the DeltaBlock and decoder #2 below
   c.tape = nullptr;
   if (tape) tape->temb_act = temb_act;
-  e->pool.put(temb);
+  if (temb) e->pool.put(temb);
   // training forward: the pool HOLDS (instead of recycling) exactly what the backward pass reads -- swish(temb), the skip
   // tensors, the bottleneck h, the timestep projections and everything the DeltaBlock + decoder #2 window returns; the encoder's
   // and decoder #1's intermediates are recycled as in inference
   e->pool.defer = (tape != nullptr);
-  e->pool.put(temb_act);
+  if (temb_act) e->pool.put(temb_act);
   e->pool.defer = false;
 
   // encoder (:485-495)
@@ -1640,7 +1671,7 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
   c.skip_part.clear();
   e->pool.defer = (tape != nullptr);                 // skips and timestep projections: read by the backward pass
   for (auto& a : skips) drop(c, a);
-  e->pool.put(c.tproj);
+  if (!pre) e->pool.put(c.tproj);
   e->pool.defer = false;
   c.tproj = nullptr;
   return 0;
@@ -1649,6 +1680,37 @@ int unet_core_ddpm(Ctx& c, const float* x_nhwc, const float* t_dev, int index, i
 __global__ void fill_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+struct FillVals { float v[256]; };
+__global__ void fill_values_kernel(float* p, const FillVals f, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = f.v[threadIdx.x];
+}
+
+// The timestep-only work of a whole loop, before the loop (asyrp_run_edit, asyrp_run_inversion): row k of `tproj` is what the two
+// launches at the head of step k's UNet evaluation would have produced for every image of the batch (see Ctx::tproj_pre).
+struct TimestepRows {
+  float *t = nullptr, *temb = nullptr, *tact = nullptr, *tproj = nullptr;
+  void release(asyrp_engine* e) {
+    for (float* p : {t, temb, tact, tproj})
+      if (p) e->pool.put(p);
+    t = temb = tact = tproj = nullptr;
+  }
+};
+int precompute_timestep_rows(Ctx& c, const std::vector<float>& ts, TimestepRows* r) {
+  asyrp_engine* e = c.e;
+  const int n_steps = (int)ts.size();
+  if (n_steps < 1) return 0;
+  TRY(e->pool.get((size_t)n_steps, &r->t));
+  TRY(e->pool.get((size_t)n_steps * e->temb_ch, &r->temb));
+  TRY(e->pool.get((size_t)n_steps * e->temb_ch, &r->tact));
+  TRY(e->pool.get((size_t)n_steps * e->tproj_total, &r->tproj));
+  for (int o = 0; o < n_steps; o += 256) {      // the values travel as kernel arguments (no host buffer outlives the call, no copy engine)
+    FillVals fv;
+    const int n = std::min(256, n_steps - o);
+    for (int i = 0; i < n; ++i) fv.v[i] = ts[o + i];
+    hipLaunchKernelGGL(fill_values_kernel, dim3(1), dim3(256), 0, c.s, r->t + o, fv, n);
+  }
+  return timestep_rows(c, r->t, n_steps, r->temb, r->tact, r->tproj);
 }
 
 // Workspace buffers are recycled without waiting, which is only safe on one in-order stream: when the caller switches
@@ -2278,10 +2340,20 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
   TRY(e->pool.get(nx, &xa));
   TRY(e->pool.get(nx, &xb));
   HIPCHK(launch_nchw_to_nhwc(x0, xa, B, 3, HW, c.s));
+  // Every timestep of the edit is known here and all images of the batch share it: the timestep embedding + MLP and every block's
+  // Linear(swish(temb)) of ALL steps are two launches now instead of two per UNet evaluation (158 per 39 + 40-step edit); step k
+  // reads row k (Ctx::tproj_pre, row pitch 0 over the images).  Same arithmetic per row as the per-step launches: bit-identical.
+  std::vector<float> ts;
+  for (int k = 1; k < n_inv; ++k) ts.push_back((float)seq_inv[k - 1]);
+  for (int k = n_gen - 1; k >= 0; --k) ts.push_back((float)seq_gen[k]);
+  TimestepRows rows;
+  TRY(precompute_timestep_rows(c, ts, &rows));
+  float* const tproj_all = rows.tproj;
+  int step_row = 0;
   // loop A — DDIM inversion (diffusion_latent.py:1034-1045): (t, t_next) = (seq[k-1], seq[k]), k = 1..n_inv-1
   for (int k = 1; k < n_inv; ++k) {
     const int t = seq_inv[k - 1], tn = seq_inv[k];
-    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    c.tproj_pre = tproj_all + (size_t)(step_row++) * e->tproj_total;
     Act a_et, a_em, a_dh, a_mid;
     TRY(unet_core(c, xa, e->d_t, -1, 0, nullptr, 0, &a_et, &a_em, &a_dh, &a_mid));
     TRY(ddim_apply(c, xa, a_et, a_em, nullptr, t, tn, 0.f, 1.f, 999, xb, nullptr));
@@ -2304,7 +2376,7 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
       ++used_noise;
       nzp = nz;
     }
-    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    c.tproj_pre = tproj_all + (size_t)(step_row++) * e->tproj_total;
     Act a_et, a_em, a_dh, a_mid;
     TRY(unet_core(c, xa, e->d_t, index, edit, hs_coeff_host, 0, &a_et, &a_em, &a_dh, &a_mid));
     TRY(ddim_apply(c, xa, a_et, a_em, nzp, t, tn, eta, 1.f, 999, xb, nullptr));
@@ -2317,6 +2389,7 @@ int asyrp_run_edit(asyrp_engine* e, const float* x0, int B, const int32_t* seq_i
   HIPCHK(launch_nhwc_to_nchw(xa, 3, x_edit, B, 3, HW, c.s));
   e->pool.put(xa); e->pool.put(xb);
   if (nz) e->pool.put(nz);
+  rows.release(e);
   return 0;
 }
 
@@ -2581,9 +2654,13 @@ int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* 
   TRY(e->pool.get(nx, &xb));
   if (x0t_tap) TRY(e->pool.get(nx, &x0o));
   HIPCHK(launch_nchw_to_nhwc(x0, xa, B, 3, HW, c.s));
+  std::vector<float> ts;
+  for (int k = 1; k < n_inv; ++k) ts.push_back((float)seq_inv[k - 1]);
+  TimestepRows rows;
+  TRY(precompute_timestep_rows(c, ts, &rows));
   for (int k = 1; k < n_inv; ++k) {
     const int t = seq_inv[k - 1], tn = seq_inv[k];
-    hipLaunchKernelGGL(fill_kernel, dim3((B + 63) / 64), dim3(64), 0, c.s, e->d_t, (float)t, B);
+    c.tproj_pre = rows.tproj + (size_t)(k - 1) * e->tproj_total;
     Act a_et, a_em, a_dh, a_mid;
     TRY(unet_core(c, xa, e->d_t, -1, 0, nullptr, 0, &a_et, &a_em, &a_dh, &a_mid));
     const int slot = (k - 1) - tap_first;
@@ -2596,6 +2673,7 @@ int asyrp_run_inversion(asyrp_engine* e, const float* x0, int B, const int32_t* 
     if (tap && x0t_tap) HIPCHK(launch_nhwc_to_nchw(x0o, 3, x0t_tap + (size_t)slot * nx, B, 3, HW, c.s));
   }
   if (x_last) HIPCHK(launch_nhwc_to_nchw(xa, 3, x_last, B, 3, HW, c.s));
+  rows.release(e);
   return 0;
 }
 
