@@ -518,3 +518,87 @@ def test_compact_fixture_storage_roundtrip(tmp_path):
             assert_close(bad.reshape(t.shape), s_)
     with pytest.raises(AssertionError):                                  # other weights under the same checkpoint name: refused
         compact.save(str(tmp_path / name), dict(full, **{"param.layer_0.conv1.weight": full["param.layer_0.conv1.weight"] + 1}))
+
+
+def test_data_parallel_sharding_bookkeeping_with_stand_in_engines(monkeypatch):
+    """data_parallel.sharded_step / sharded_edit on CPU tensors with stand-ins for torch's CUDA scatter / threads / gather and for the
+    engine: the batch is cut as torch.chunk cuts it, every chunk gets ITS rows of the noise (batch dimension 1 of the
+    [n_eta, B, ...] stack), of an injected delta_h and of a per-image coefficient table, chunks run on the device their wrapper entry
+    names, results come back in batch order, an injected delta_h is returned as the caller's own object, want_latent gathers both
+    tensors.  (The real wrappers run in tests/test_gpu_data_parallel.py; this is the N > 1 logic the driver can check without a GPU.)"""
+    import threading
+    from asyrp_official_amd import data_parallel as dp
+
+    def fake_scatter(t, ids, dim=0):
+        return tuple(torch.chunk(t, len(ids), dim=dim))
+
+    seen = []
+
+    def fake_parallel_apply(fns, inputs, kwargs_tup=None, devices=None):
+        out = [None] * len(fns)
+
+        def work(i):
+            seen.append((devices[i], threading.get_ident()))
+            out[i] = fns[i](*inputs[i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return out
+
+    def fake_gather(outs, dev):
+        first = outs[0]
+        if first is None:
+            return None
+        if isinstance(first, torch.Tensor):
+            return torch.cat(outs, 0)
+        return type(first)(fake_gather([o[i] for o in outs], dev) for i in range(len(first)))
+
+    monkeypatch.setattr(dp, "scatter", fake_scatter)
+    monkeypatch.setattr(dp, "parallel_apply", fake_parallel_apply)
+    monkeypatch.setattr(dp, "gather", fake_gather)
+
+    class FakeEngine:
+        def ddim_step(self, x, noise=None, delta_h=None, t=0, t_next=0, **kw):
+            nz = noise if noise is not None else torch.zeros_like(x)
+            dh = delta_h if delta_h is not None else (x[:, :1, :2, :2] * 3 if kw.get("apply_edit") else None)
+            return x * 2 + nz + t, x - nz, dh, x[:, :1, :1, :1] + t_next
+
+        def run_edit(self, x, seq_inv, seq_gen, noise=None, hs_coeff=(1.0, 1.0), want_latent=False, **kw):
+            per = hs_coeff if isinstance(hs_coeff[0], (tuple, list)) else [hs_coeff] * x.shape[0]
+            assert len(per) == x.shape[0]
+            c = torch.tensor([float(p_[1]) for p_ in per]).view(-1, 1, 1, 1)
+            y = x * c + (noise.sum(0) if noise is not None else 0) + len(seq_inv) + 10 * len(seq_gen)
+            return (y, x + 1) if want_latent else y
+
+    class FakeModel:
+        def _ready_engine(self, x):
+            return FakeEngine()
+
+    class Wrapper(torch.nn.DataParallel):
+        def __init__(self):          # no CUDA here: only the attributes the sharding code reads
+            torch.nn.Module.__init__(self)
+            self.device_ids, self.output_device = [0, 1, 2], 0
+
+    w, m, eng = Wrapper(), FakeModel(), FakeEngine()
+    assert dp.wrapper_devices(w) == [0, 1, 2]
+    B = 7
+    x = torch.arange(B * 3 * 4 * 4, dtype=torch.float32).reshape(B, 3, 4, 4)
+    nz = torch.randn(B, 3, 4, 4)
+    dh = torch.randn(B, 1, 2, 2)
+    got = dp.sharded_step(w, m, x, noise=nz, delta_h=None, t=5, t_next=4, apply_edit=True)
+    want = eng.ddim_step(x, noise=nz, t=5, t_next=4, apply_edit=True)
+    assert all(torch.equal(g, v) for g, v in zip(got, want))
+    assert sorted(d for d, _ in seen) == [0, 1, 2] and len({tid for _, tid in seen}) == 3          # one thread per wrapper device
+    got = dp.sharded_step(w, m, x, noise=None, delta_h=dh, t=5, t_next=4, apply_edit=True)
+    assert got[2] is dh and torch.equal(got[0], x * 2 + 5)                                          # the caller's own delta_h object
+    got = dp.sharded_step(w, m, x, t=5, t_next=4, apply_edit=False)
+    assert got[2] is None
+    # both loops: noise stack [n_eta, B, ...] split along its batch dimension, one coefficient tuple per image split with the batch
+    stack = torch.randn(2, B, 3, 4, 4)
+    tuples = [(1.0, 0.5 * i) for i in range(B)]
+    got, got_T = dp.sharded_edit(w, m, x, [0, 1], [0, 1, 2], noise=stack, hs_coeff=tuples, want_latent=True, t_edit=1)
+    want, want_T = eng.run_edit(x, [0, 1], [0, 1, 2], noise=stack, hs_coeff=tuples, want_latent=True)
+    assert torch.equal(got, want) and torch.equal(got_T, want_T)
+    assert torch.equal(dp.sharded_edit(w, m, x[:2], [], [0], hs_coeff=(1.0, 2.0)), eng.run_edit(x[:2], [], [0], hs_coeff=(1.0, 2.0)))
+    with pytest.raises(ValueError):
+        dp.sharded_edit(w, m, x, [], [0], hs_coeff=tuples[:3])
