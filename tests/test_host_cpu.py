@@ -588,7 +588,7 @@ def test_data_parallel_sharding_bookkeeping_with_stand_in_engines(monkeypatch):
     got = dp.sharded_step(w, m, x, noise=nz, delta_h=None, t=5, t_next=4, apply_edit=True)
     want = eng.ddim_step(x, noise=nz, t=5, t_next=4, apply_edit=True)
     assert all(torch.equal(g, v) for g, v in zip(got, want))
-    assert sorted(d for d, _ in seen) == [0, 1, 2] and len({tid for _, tid in seen}) == 3          # one thread per wrapper device
+    assert sorted(d for d, _ in seen) == [0, 1, 2]                                                  # one chunk per wrapper device
     got = dp.sharded_step(w, m, x, noise=None, delta_h=dh, t=5, t_next=4, apply_edit=True)
     assert got[2] is dh and torch.equal(got[0], x * 2 + 5)                                          # the caller's own delta_h object
     got = dp.sharded_step(w, m, x, t=5, t_next=4, apply_edit=False)
