@@ -132,7 +132,8 @@ class HipUNet(nn.Module):
         for slot in slots:
             with slot.lock:
                 if slot.engine is not None:
-                    slot.engine.close()
+                    with slot.engine.lock:          # not while another thread is inside a call on it
+                        slot.engine.close()
                 slot.engine, slot.sig, slot.uploaded = None, None, {}
 
     def _apply(self, fn, *a, **k):
@@ -184,8 +185,9 @@ class HipUNet(nn.Module):
                 if slot.engine is not None:
                     # a larger batch / another DeltaBlock count: the SAME Engine object gets a new native handle, so that references a
                     # caller took earlier (`eng = model.engine()`) stay valid instead of pointing at a destroyed engine
-                    slot.engine.close()
-                    slot.engine.__init__(src._make_cfg(src._n_delta), sig[2], idx)
+                    with slot.engine.lock:          # not while another thread is inside a call on the old handle
+                        slot.engine.close()
+                        slot.engine.__init__(src._make_cfg(src._n_delta), sig[2], idx)
                 else:
                     slot.engine = Engine(src._make_cfg(src._n_delta), sig[2], idx)
                 slot.uploaded = {}
