@@ -8,10 +8,18 @@
 //     y[q][co]            = bias[co] + sum_tap Z[q + offset(tap)][tap*Cout + co]        a 9-term stencil over the halo pixels
 // so the matrix work drops 6.5x (f16x3 split products as everywhere else): 365 us instead of 587 us per launch at B = 32
 // (rocprofv3, same box).  The 6-channel iDDPM head needs two N tiles and measured equal to the tile path, which it keeps.
-// One workgroup = an 8 x 16 output patch of one image (10 x 18 halo pixels = 6 MFMA row tiles), 4 waves; the whole weight image
-// (<= 32 KB) sits in LDS for the launch; Z goes through LDS (aliasing the staging buffers) for the stencil.
-// A 16 x 16 patch (halo overhead 1.27x instead of 1.41x) measured slower, 41 vs 45 TFLOP/s inside the edit: 58 KB of LDS leaves two
-// workgroups per CU instead of four (gpurun_out/r4prep_e, round-4 prep).
+// One workgroup = 4 waves on an output patch of one image; Z goes through LDS (aliasing the staging buffers) for the stencil.
+//   * 14 x 14 patch (round 6, the 3-channel head): the 16 x 16 halo is exactly 256 pixels = 8 MFMA row tiles (two per wave) = 512
+//     staging items (two per thread, none idle): 2.61 staged items per output pixel instead of the 8 x 16 patch's 4.0 (1.31 x halo
+//     instead of 1.41 x, and no half-empty second staging round on 360 items); every lane fetches its B fragments of a chunk from the
+//     L2-hot weight image beside the chunk's activation loads, so the weights need no LDS: 34 KB, four workgroups per CU.
+//     323 -> 298 us per launch at B = 32, same box, interleaved (profiles/r06m_*); bit-identical to the 8 x 16 form (same products in
+//     the same order per output; sha256 of the outputs on five shapes, gpurun_out/r06n/bits.txt).
+//   * 8 x 16 patch (10 x 18 halo pixels = 6 row tiles), the whole weight image (<= 32 KB) in LDS for the launch: the 6-channel iDDPM
+//     head on two N tiles, and maps smaller than a 14 x 14 patch.
+// A 16 x 16 patch (halo overhead 1.27x) measured slower, 41 vs 45 TFLOP/s inside the edit: 58 KB of LDS leaves two workgroups per CU
+// instead of four (gpurun_out/r4prep_e, round-4 prep).  Round 6 also measured a persistent form and a form fed straight from global
+// memory without LDS staging: both slower (scripts/experiments/conv_out_*_NEGATIVE.patch).
 #include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
@@ -23,8 +31,21 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CO_PH = 8, CO_PW = 16, CO_TH = CO_PH + 2, CO_TW = CO_PW + 2, CO_NPIX = CO_TH * CO_TW;   // 180 halo pixels
-constexpr int CO_MT = (CO_NPIX + 31) / 32;                                                             // 6 row tiles
+// Patch geometry.  CoPatch<8, 16>: the round-2 patch (10 x 18 = 180 halo pixels: 6 row tiles on 4 waves, 360 staging items on 256
+// threads).  CoPatch<14, 14> (round 6): the 16 x 16 halo is exactly 256 pixels = 8 row tiles (two per wave) = 512 staging items (two
+// per thread, none idle): 2.61 staged items per output pixel instead of 4.0 (1.31 x halo instead of 1.41 x, and no half-empty
+// second staging round) -- the kernel's time is its staging arithmetic.
+// WLDS: the weight image lives in LDS for the launch (the 8 x 16 form), or -- false -- every lane fetches its two 16-byte B fragments
+// of a chunk from the L2-hot image beside the chunk's activation loads (the 14 x 14 form: 34 KB of LDS instead of 49, four
+// workgroups per CU instead of three).
+template <int PH_, int PW_, bool WLDS_ = true>
+struct CoPatch {
+  static constexpr int PH = PH_, PW = PW_, TH = PH + 2, TW = PW + 2, NPIX = TH * TW, MT = (NPIX + 31) / 32;
+  static constexpr bool WLDS = WLDS_;
+};
+using CoP816 = CoPatch<8, 16>;
+using CoP1414 = CoPatch<14, 14, false>;
+using CoP1414W = CoPatch<14, 14, true>;
 constexpr float CO_HMAX = 65504.0f;
 
 __device__ __forceinline__ float co_silu(float v) {
@@ -51,14 +72,17 @@ __device__ __forceinline__ void co_split8(const float (&v)[8], h8& hi, h8& lo) {
 // TN = N tiles of 32 columns (9*Cout <= 32*TN).  Weight image = launch_pack_f16x3 of the equivalent 1x1 conv
 // w1[n = tap*Cout + co][ci]: [chunk][unit 4][cout_pad][8 halfs].
 // NP = matrix products per term: 3 (two-term split) or 1 (conv_math "f16": x_hi * w_hi only).
-template <int TN, int NP = 3>
+template <int TN, int NP = 3, class PT = CoP816>
 __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
+  constexpr int CO_PH = PT::PH, CO_PW = PT::PW, CO_TW = PT::TW, CO_NPIX = PT::NPIX, CO_MT = PT::MT;
+  constexpr bool WLDS = PT::WLDS;
+  static_assert(WLDS || TN == 1, "B fragments from global memory: one N tile");
   constexpr int NT = 256, NW = 4, BN = 32 * TN;
   constexpr int A_BYTES = CO_NPIX * 64;                 // [4 units][NPIX][16 B]
   constexpr int ZLD = BN + 1;                           // padded row of the Z tile (floats)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch = p.Cin >> 4;
-  const int W_BYTES = nch * 4 * BN * 16;
+  const int W_BYTES = WLDS ? nch * 4 * BN * 16 : 0;
   char* const Ws = smem;                                // [chunk][4][BN][16 B]
   char* const As = smem + W_BYTES;                      // 2 x A_BYTES
   float* const Zs = reinterpret_cast<float*>(smem);     // after the K loop: [CO_MT*32][ZLD] floats (aliases Ws / As)
@@ -80,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
     Ps[p.Cin + i] = psh[i];
   }
   // ---- weights -> LDS (once) ----
-  {
+  if (WLDS) {
     const char* wpk = reinterpret_cast<const char*>(p.wpk);
     for (int i = tid; i < nch * 4 * BN; i += NT) {
       const int n = i % BN, cu = i / BN;                 // cu = chunk*4 + unit
@@ -115,6 +139,17 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
       const float* src = base + (long long)max(aoff[i], 0) * p.lda0;
       areg[set][i][0] = *reinterpret_cast<const float4*>(src);
       areg[set][i][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
+  };
+  // !WLDS: this lane's B fragments (column lane & 31, k group lane >> 5) of a chunk, hi and lo planes, straight from the packed image;
+  // chunk c + 2's are requested right AFTER chunk c's matrix instructions have consumed the register set they land in
+  h8 breg[2][2];
+  auto gloadB = [&](int chunk, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    if (!WLDS) {
+      const char* b = reinterpret_cast<const char*>(p.wpk) + (((size_t)chunk * 4 + (lane >> 5)) * p.cout_pad + (lane & 31)) * 16;
+      breg[set][0] = *reinterpret_cast<const h8*>(b);
+      if (NP == 3) breg[set][1] = *reinterpret_cast<const h8*>(b + 2 * (size_t)p.cout_pad * 16);
     }
   };
   auto stage = [&](int chunk, int buf, auto set_c) {
@@ -161,7 +196,8 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  auto mma_chunk = [&](int chunk) {
+  auto mma_chunk = [&](int chunk, auto set_c) {
+    constexpr int set = decltype(set_c)::value;          // == chunk & 1
     const char* A = As + (chunk & 1) * A_BYTES + kh * CO_NPIX * 16;
     const char* B = Ws + ((size_t)chunk * 4 + kh) * BN * 16 + (lane & 31) * 16;
 #pragma unroll
@@ -170,10 +206,10 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
       const h8 ah = *reinterpret_cast<const h8*>(A + arow[t] * 16);
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const h8 bh = *reinterpret_cast<const h8*>(B + n * 32 * 16);
+        const h8 bh = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16) : breg[set][0];
         if (NP == 3) {
           const h8 al = *reinterpret_cast<const h8*>(A + arow[t] * 16 + 2 * CO_NPIX * 16);
-          const h8 bl = *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16);
+          const h8 bl = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16) : breg[set][1];
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][n], 0, 0, 0);
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][n], 0, 0, 0);
@@ -185,7 +221,9 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   };
   // chunk c lives in register set c & 1 until it is staged; loads past the last chunk re-read it (static load counts)
   gload(0, S0{});
+  gloadB(0, S0{});
   gload(min(1, nch - 1), S1{});
+  gloadB(min(1, nch - 1), S1{});
   __syncthreads();   // the scale / shift rows in Ps were written by other waves (without this barrier waves 1-3 staged chunk 0 from
                      // whatever the LDS held: a few-per-mille run-to-run difference in some tiles of some images, found in round 4
                      // by running the same batch twice -- scripts/batch_invariance_probe.py)
@@ -196,11 +234,13 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
     // Every iteration issues the same loads and the same staging pass (past the end: the last chunk again, into the buffer nobody
     // reads any more), so the body is straight-line code with static counts.
     gload(min(chunk + 2, nch - 1), S0{});
-    mma_chunk(chunk);
+    mma_chunk(chunk, S0{});
+    gloadB(min(chunk + 2, nch - 1), S0{});
     stage(chunk + 1, 1, S1{});
     __syncthreads();
     gload(min(chunk + 3, nch - 1), S1{});
-    mma_chunk(chunk + 1);
+    mma_chunk(chunk + 1, S1{});
+    gloadB(min(chunk + 3, nch - 1), S1{});
     stage(min(chunk + 2, nch - 1), 0, S0{});
     __syncthreads();
   }
@@ -235,10 +275,17 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   }
 }
 
-size_t conv_out_smem(int Cin, int TN) {
-  const size_t w = (size_t)(Cin / 16) * 4 * 32 * TN * 16, a = 2 * (size_t)CO_NPIX * 64;
-  const size_t z = (size_t)CO_MT * 32 * (32 * TN + 1) * sizeof(float), ps = 2 * (size_t)Cin * sizeof(float);
+template <class PT>
+static size_t conv_out_smem_p(int Cin, int TN) {
+  const size_t w = PT::WLDS ? (size_t)(Cin / 16) * 4 * 32 * TN * 16 : 0, a = 2 * (size_t)PT::NPIX * 64;
+  const size_t z = (size_t)PT::MT * 32 * (32 * TN + 1) * sizeof(float), ps = 2 * (size_t)Cin * sizeof(float);
   return (w + a + ps > z) ? w + a + ps : z;
+}
+size_t conv_out_smem(int Cin, int TN) { return conv_out_smem_p<CoP816>(Cin, TN); }
+// A/B switch (profiling build): ASYRP_CONV_OUT_PATCH=816 keeps the 8 x 16 patch for the 3-channel head
+static bool conv_out_patch1414() {
+  static const bool on = [] { const char* e = ab_env("ASYRP_CONV_OUT_PATCH"); return !(e && e[0] == '8'); }();
+  return on;
 }
 
 bool conv_out_two_tiles() {
@@ -258,28 +305,35 @@ bool conv_out_supported(const GemmArgs& a) {
   return a.Cout * 9 <= 64 && conv_out_two_tiles() && conv_out_smem(a.Cin, 2) <= 64 * 1024;
 }
 
-template <int NP, int TN = 1>
+template <int NP, int TN = 1, class PT = CoP816>
 static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
-  const size_t smem = conv_out_smem(a.Cin, TN);
-  dim3 grid(((a.Hout + CO_PH - 1) / CO_PH) * ((a.Wout + CO_PW - 1) / CO_PW), 1, a.Z), block(256);
+  const size_t smem = conv_out_smem_p<PT>(a.Cin, TN);
+  dim3 grid(((a.Hout + PT::PH - 1) / PT::PH) * ((a.Wout + PT::PW - 1) / PT::PW), 1, a.Z), block(256);
   if (smem > 64 * 1024) {   // once per process and device (idempotent flag, as launch_k32)
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_out_kernel<TN, NP, PT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((conv_out_kernel<TN, NP>), grid, block, smem, s, a);
+  hipLaunchKernelGGL((conv_out_kernel<TN, NP, PT>), grid, block, smem, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
   if (!conv_out_supported(a)) return hipErrorInvalidValue;
-  if (a.Cout * 9 > 32) return a.np == 1 ? launch_conv_out_np<1, 2>(a, s) : launch_conv_out_np<3, 2>(a, s);
+  if (a.Cout * 9 > 32) {   // two N tiles (the 6-channel iDDPM head): the 14 x 14 patch with the weights in LDS (67 KB: two workgroups per CU, as before)
+    if (conv_out_patch1414() && a.Hout >= 14 && a.Wout >= 14)
+      return a.np == 1 ? launch_conv_out_np<1, 2, CoP1414W>(a, s) : launch_conv_out_np<3, 2, CoP1414W>(a, s);
+    return a.np == 1 ? launch_conv_out_np<1, 2>(a, s) : launch_conv_out_np<3, 2>(a, s);
+  }
+  // one N tile (the 3-channel head): the 14 x 14 patch where the layer has at least a patch of pixels, else the 8 x 16 one
+  if (conv_out_patch1414() && a.Hout >= 14 && a.Wout >= 14)
+    return a.np == 1 ? launch_conv_out_np<1, 1, CoP1414>(a, s) : launch_conv_out_np<3, 1, CoP1414>(a, s);
   return a.np == 1 ? launch_conv_out_np<1>(a, s) : launch_conv_out_np<3>(a, s);
 }
 
