@@ -91,9 +91,14 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int zo = blockIdx.z;
+  // Workgroups go to the 8 XCDs round-robin by linear id.  xmap: XCD k takes a contiguous range of (image, patch) pairs, so the
+  // patches of an image -- which share their halo rows and columns -- meet in ONE L2 (with the identity map a 14 x 14 patch's
+  // neighbours sit on other XCDs and every halo pixel is fetched from HBM again: 1.41 x the algorithmic bytes by counters)
+  int lin = blockIdx.x + gridDim.x * blockIdx.z;
+  if (p.xmap) lin = (lin & 7) * ((int)(gridDim.x * gridDim.z) >> 3) + (lin >> 3);
+  const int zo = lin / (int)gridDim.x, patch = lin - zo * (int)gridDim.x;
   const int tiles_x = (p.Wout + CO_PW - 1) / CO_PW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int ty = patch / tiles_x, tx = patch - ty * tiles_x;
   const int oy0 = ty * CO_PH, ox0 = tx * CO_PW;
   const float* __restrict__ a0 = p.a0 + (long long)zo * p.a0_zo;
   const float* __restrict__ ps = p.pscale + (long long)zo * p.Cin;
@@ -320,7 +325,9 @@ static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
       if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((conv_out_kernel<TN, NP, PT>), grid, block, smem, s, a);
+  GemmArgs ax = a;
+  ax.xmap = (xcd_map_enabled() && ((long long)grid.x * grid.z) % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((conv_out_kernel<TN, NP, PT>), grid, block, smem, s, ax);
   return hipGetLastError();
 }
 
