@@ -76,7 +76,6 @@ template <int TN, int NP = 3, class PT = CoP816>
 __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   constexpr int CO_PH = PT::PH, CO_PW = PT::PW, CO_TW = PT::TW, CO_NPIX = PT::NPIX, CO_MT = PT::MT;
   constexpr bool WLDS = PT::WLDS;
-  static_assert(WLDS || TN == 1, "B fragments from global memory: one N tile");
   constexpr int NT = 256, NW = 4, BN = 32 * TN;
   constexpr int A_BYTES = CO_NPIX * 64;                 // [4 units][NPIX][16 B]
   constexpr int ZLD = BN + 1;                           // padded row of the Z tile (floats)
@@ -148,13 +147,16 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
   };
   // !WLDS: this lane's B fragments (column lane & 31, k group lane >> 5) of a chunk, hi and lo planes, straight from the packed image;
   // chunk c + 2's are requested right AFTER chunk c's matrix instructions have consumed the register set they land in
-  h8 breg[2][2];
+  h8 breg[2][TN][2];
   auto gloadB = [&](int chunk, auto set_c) {
     constexpr int set = decltype(set_c)::value;
     if (!WLDS) {
       const char* b = reinterpret_cast<const char*>(p.wpk) + (((size_t)chunk * 4 + (lane >> 5)) * p.cout_pad + (lane & 31)) * 16;
-      breg[set][0] = *reinterpret_cast<const h8*>(b);
-      if (NP == 3) breg[set][1] = *reinterpret_cast<const h8*>(b + 2 * (size_t)p.cout_pad * 16);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        breg[set][n][0] = *reinterpret_cast<const h8*>(b + n * 32 * 16);
+        if (NP == 3) breg[set][n][1] = *reinterpret_cast<const h8*>(b + n * 32 * 16 + 2 * (size_t)p.cout_pad * 16);
+      }
     }
   };
   auto stage = [&](int chunk, int buf, auto set_c) {
@@ -211,10 +213,10 @@ __global__ void __launch_bounds__(256, 2) conv_out_kernel(const GemmArgs p) {
       const h8 ah = *reinterpret_cast<const h8*>(A + arow[t] * 16);
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const h8 bh = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16) : breg[set][0];
+        const h8 bh = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16) : breg[set][n][0];
         if (NP == 3) {
           const h8 al = *reinterpret_cast<const h8*>(A + arow[t] * 16 + 2 * CO_NPIX * 16);
-          const h8 bl = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16) : breg[set][1];
+          const h8 bl = WLDS ? *reinterpret_cast<const h8*>(B + n * 32 * 16 + 2 * BN * 16) : breg[set][n][1];
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][n], 0, 0, 0);
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][n], 0, 0, 0);
           acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][n], 0, 0, 0);
@@ -304,10 +306,11 @@ bool conv_out_supported(const GemmArgs& a) {
   if (!(a.ks == 3 && a.stride == 1 && !a.ups && !a.a1 && a.wpk && a.pscale && a.silu && !a.resid && !a.chan_add && !a.stats)) return false;
   if (!((a.Cin & 31) == 0 && a.Cin <= 256 && (a.lda0 & 3) == 0 && a.Hin == a.Hout && a.Win == a.Wout)) return false;
   if (a.Cout * 9 <= 32) return true;                                  // one N tile (Cout = 3)
-  // two N tiles (Cout = 6): only where the A/B evidence is (AFHQ head, Cin = 128) and two workgroups still fit a CU -- at Cin = 256
-  // (ImageNet-ADM head) the form needs ~90 KB of LDS, one workgroup per CU, and measured 39 TFLOP/s, below the implicit-GEMM
-  // tile: that head stays on the tile
-  return a.Cout * 9 <= 64 && conv_out_two_tiles() && conv_out_smem(a.Cin, 2) <= 64 * 1024;
+  // two N tiles (Cout = 6): where two workgroups still fit a CU.  AFHQ head (Cin = 128): weights in LDS.  At Cin = 256 (ImageNet-ADM
+  // head) the weights-in-LDS forms need ~90 KB, one workgroup per CU, and measured 39 TFLOP/s, below the implicit-GEMM tile
+  // (ADVICE r04); since round 6 that head runs on the 14 x 14 patch with its B fragments from the L2-hot image (67 KB, two per CU)
+  if (!(a.Cout * 9 <= 64 && conv_out_two_tiles())) return false;
+  return conv_out_smem(a.Cin, 2) <= 64 * 1024 || (conv_out_patch1414() && a.Hout >= 14 && a.Wout >= 14);
 }
 
 template <int NP, int TN = 1, class PT = CoP816>
@@ -334,8 +337,11 @@ static hipError_t launch_conv_out_np(const GemmArgs& a, hipStream_t s) {
 hipError_t launch_conv_out(const GemmArgs& a, hipStream_t s) {
   if (!conv_out_supported(a)) return hipErrorInvalidValue;
   if (a.Cout * 9 > 32) {   // two N tiles (the 6-channel iDDPM head): the 14 x 14 patch with the weights in LDS (67 KB: two workgroups per CU, as before)
-    if (conv_out_patch1414() && a.Hout >= 14 && a.Wout >= 14)
+    if (conv_out_patch1414() && a.Hout >= 14 && a.Wout >= 14) {
+      if (conv_out_smem(a.Cin, 2) > 64 * 1024)   // Cin = 256: no room for the weights in LDS
+        return a.np == 1 ? launch_conv_out_np<1, 2, CoP1414>(a, s) : launch_conv_out_np<3, 2, CoP1414>(a, s);
       return a.np == 1 ? launch_conv_out_np<1, 2, CoP1414W>(a, s) : launch_conv_out_np<3, 2, CoP1414W>(a, s);
+    }
     return a.np == 1 ? launch_conv_out_np<1, 2>(a, s) : launch_conv_out_np<3, 2>(a, s);
   }
   // one N tile (the 3-channel head): the 14 x 14 patch where the layer has at least a patch of pixels, else the 8 x 16 one
